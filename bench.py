@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- MI355X Enhanced-RAISR hot path, BASELINE.json metric: output-Y megapixels/s.
+
+Workload (config.workload): BASELINE.json configs[1] -- 1080p -> 4K 2x, filters_2x/filters_highres,
+1-pass, 8-bit, CountOfBitsChanged blending, AVX-512-exact numerics.  A "step" is one pass of the hot
+path (cheap upscale -> structure-tensor hash -> 11x11 filter -> CT blend) over one batch of
+`--frames-per-step` synthetic 1080p Y planes that are already resident in HBM.  One process per
+GPU; frames are sharded across ranks with no data-path collective (weak scaling); the only
+collective is one RCCL broadcast of the packed filter-bank blob at start-up.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     -- dominant kernel (k_hash): algorithmic bytes per launch / average launch duration,
+                  measured with HIP events on the kernel's own stream over the timed region
+  cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-super-resolution-library_amd"))
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--lanes", type=int, default=4, help="frames in flight per GPU (one context+stream each)")
+    ap.add_argument("--passes", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+IN_W, IN_H, OUT_W, OUT_H = 1920, 1080, 3840, 2160
+FOLDER = os.path.join(ROOT, "filters_2x", "filters_highres")
+ALGO_BYTES_PER_FRAME = IN_W * IN_H + OUT_W * OUT_H          # 10 368 000 B
+HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
+
+
+def cpu_baseline(sample_frames):
+    """CPU oracle (test infrastructure, oracle/) timed on the host cores: kind "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    import synth
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    O.lib()
+    p1 = O.make_pass(O.Model(FOLDER, 8, 1), 8, False, O.ASM_AVX512)
+    frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + i) for i in range(sample_frames)]
+    O.process_y(frames[0][:128, :256], 512, 256, p1)         # warm the thread pool / page in
+    t0 = time.perf_counter()
+    for f in frames:
+        O.process_y(f, OUT_W, OUT_H, p1)
+    dt = time.perf_counter() - t0
+    return {"value": round(OUT_W * OUT_H * sample_frames / dt / 1e6, 3), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_frames} synthetic 1080p->4K frames, 1-pass, scalar C oracle with OpenMP row bands, {dt:.2f}s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import raisr_hip as R
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- model: rank 0 reads the files and packs the device blob; RCCL broadcast to the others ----
+    passes = args.passes
+    blobs = []
+    for p in range(passes):
+        if rank == 0:
+            bank, qstr, qcoh, qa = R.read_model_folder(FOLDER, 8, p + 1)
+            blob = torch.from_numpy(R.pack_model_blob(bank, qstr, qcoh, qa)).to(dev)
+        else:
+            blob = torch.empty(R.lib().raisr_hip_model_blob_bytes(216, 4), dtype=torch.uint8, device=dev)
+        if world > 1:
+            dist.broadcast(blob, src=0)
+        blobs.append(blob)
+    torch.cuda.synchronize()
+
+    lanes = []
+    for _ in range(args.lanes):
+        d = R.RaisrDevice(local_rank)
+        for p in range(passes):
+            d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
+        d.configure(IN_W, IN_H, OUT_W, OUT_H, bits=8, passes=passes, mode=1, hash_variant=R.HASH_AVX512)
+        lanes.append(d)
+
+    # ---- synthetic input, resident in HBM before the timed region ----
+    nf = args.frames_per_step
+    uniq = min(nf, 8)
+    host_frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + rank * 1000 + i) for i in range(uniq)]
+    d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
+    d_out = [torch.empty((OUT_H, OUT_W), dtype=torch.uint8, device=dev) for _ in range(args.lanes)]
+    torch.cuda.synchronize()
+
+    def step():
+        for f in range(nf):
+            ln = f % args.lanes
+            lanes[ln].process_y(d_in[f % uniq].data_ptr(), IN_W, d_out[ln].data_ptr(), OUT_W)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timing = not args.no_kernel_timing
+    if timing:
+        for d in lanes:
+            d.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel event timings (rank 0's lanes)
+    kern = {}
+    if timing:
+        for d in lanes:
+            for k, v in d.timing_read().items():
+                e = kern.setdefault(k, {"total_ms": 0.0, "count": 0})
+                e["total_ms"] += v["total_ms"]; e["count"] += v["count"]
+            d.timing_enable(False)
+
+    frames_total = args.steps * nf * world
+    mp_s = OUT_W * OUT_H * frames_total / dt / 1e6
+
+    if rank == 0:
+        roofline = None
+        kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
+        if "k_hash" in kern and kern["k_hash"]["count"]:
+            avg_s = kern["k_hash"]["total_ms"] / kern["k_hash"]["count"] * 1e-3
+            achieved = ALGO_BYTES_PER_FRAME / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("k_hash_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "k_hash", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                        "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME,
+                        "note": "path is fp32-VALU bound (~1 kFLOP per output pixel vs 1.25 compulsory bytes); "
+                                "HBM fraction is reported as required, VALU utilisation is the binding figure (DESIGN.md)"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(args.cpu_sample_frames)
+            except Exception as e:  # the baseline is reported data, never a reason to lose the GPU line
+                cpu = {"value": None, "unit": "MP/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        line = {
+            "metric": "megapixels/sec (Y-plane) 1080p->4K 2x RAISR",
+            "value": round(mp_s, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1080p->4K 2x, filters_2x/filters_highres, {passes}-pass, 8-bit, CT blend, "
+                                   "AVX512-exact numerics, frames resident in HBM",
+                       "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
+                       "parallelism": f"frame-shard x{world}"},
+            "kernels_avg_ms": kernels_ms,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+    for d in lanes:
+        d.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/*
+ * raisr_hip.h -- thin C ABI between host code and the MI355X (gfx950) HIP kernels of the
+ * Enhanced-RAISR Y-plane hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * This is the device boundary that replaces the reference's per-band CPU hot loop:
+ *   raisr_hip_process_*      <->  processSegment()            reference Library/Raisr.cpp:890-1289
+ *                                 as fanned out by RNLProcess  Library/Raisr.cpp:1294-1397
+ *   raisr_hip_resize_plane   <->  IPPResize(8|16) call sites   Library/Raisr.cpp:947-958,1373-1388
+ *   raisr_hip_set_model      <->  result of ReadTrainedData    Library/Raisr.cpp:246-433
+ *   raisr_hip_configure      <->  RNLInit parameter state      Library/Raisr.cpp:1409-1679
+ *                                 + RNLSetRes resources         Library/Raisr.cpp:1681-1829
+ * The reference-compatible C API (RNLHandler_*, include/RaisrHandler.h) is implemented on top of
+ * these entry points in csrc/raisr_api.cpp; a foreign-language binding (ctypes, cgo, JNI) can bind
+ * either layer.
+ *
+ * All functions return 0 on success, a negative RAISR_HIP_E* code otherwise, and never throw.
+ * A context owns one HIP stream-ordered set of scratch planes ("lane"): use one context per
+ * in-flight frame to overlap frames; contexts on one device may be used from different threads.
+ */
+#ifndef RAISR_HIP_H
+#define RAISR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAISR_HIP_OK            0
+#define RAISR_HIP_EINVAL      (-1)   /* bad argument / unsupported configuration */
+#define RAISR_HIP_ENODEV      (-2)   /* no usable gfx950 device / HIP runtime failure at init */
+#define RAISR_HIP_ENOMEM      (-3)   /* device allocation failed */
+#define RAISR_HIP_ESTATE      (-4)   /* call order violated (e.g. process before configure) */
+#define RAISR_HIP_ERUNTIME    (-5)   /* a HIP call failed; see raisr_hip_last_error() */
+
+/* Hash-variant selection, mirrors the reference's ASMType semantics (RaisrDefaults.h:37-44):
+ * which x86 hash flavour the bit-exact path reproduces. */
+#define RAISR_HIP_HASH_AVX2     1    /* all columns use the AVX2 hash (rcpps/rsqrtps)           */
+#define RAISR_HIP_HASH_AVX512   2    /* AVX-512 hash + AVX2 re-hash of the tail columns          */
+#define RAISR_HIP_HASH_FP16     5    /* AVX512-FP16 pipeline (binary16 arithmetic)               */
+
+#define RAISR_HIP_BLEND_RANDOMNESS 1 /* BlendingMode, RaisrDefaults.h:31-35 */
+#define RAISR_HIP_BLEND_COUNT      2
+
+#define RAISR_HIP_TIE_HALF_UP   0    /* cheap-upscale rounding of exact .5 ties (build-defined) */
+#define RAISR_HIP_TIE_HALF_EVEN 1
+
+typedef struct raisr_hip_ctx raisr_hip_ctx;
+
+typedef struct raisr_hip_config {
+    int in_width, in_height;       /* Y plane, input  */
+    int out_width, out_height;     /* Y plane, output */
+    int bits;                      /* 8, 10 or 16; samples are u8 (bits==8) else u16 LE */
+    int clamp_lo, clamp_hi;        /* gMin/gMax of RNLInit (16..235, 64..940, full range) */
+    int passes;                    /* 1 or 2 */
+    int two_pass_mode;             /* 1: upscale in pass 1; 2: upscale in pass 2 */
+    int hash_variant;              /* RAISR_HIP_HASH_* */
+    int blending;                  /* RAISR_HIP_BLEND_* */
+    int use_pixel_type;            /* 1 when ratio == 2.0 (4 filter phases), else 0 */
+    int tie_rule;                  /* RAISR_HIP_TIE_* */
+} raisr_hip_config;
+
+/* Lifetime ------------------------------------------------------------------------------------ */
+int  raisr_hip_device_count(void);
+int  raisr_hip_create(raisr_hip_ctx **out, int device_index);
+void raisr_hip_destroy(raisr_hip_ctx *ctx);
+const char *raisr_hip_last_error(void);        /* thread-local text of the last failure */
+const char *raisr_hip_version(void);
+
+/* Model -------------------------------------------------------------------------------------
+ * bank: [hashkeys][pixel_types][121] fp32 in file order (filterbin payload); thresholds as read
+ * from the Qfactor files.  pass_index 0 = first pass, 1 = second pass ("_2" files).
+ * The packed device blob (bank padded to 128 taps + thresholds) can be exported/imported so that
+ * one rank loads the files and the others receive the blob by an RCCL broadcast. */
+int    raisr_hip_set_model(raisr_hip_ctx *ctx, int pass_index, const float *bank,
+                           int hashkeys, int pixel_types, const float qstr[2], const float qcoh[2],
+                           int quant_angle);
+size_t raisr_hip_model_blob_bytes(int hashkeys, int pixel_types);
+int    raisr_hip_pack_model_blob(void *host_blob, const float *bank, int hashkeys, int pixel_types,
+                                 const float qstr[2], const float qcoh[2], int quant_angle);
+int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const void *device_blob,
+                                       size_t bytes, void *stream);
+
+/* Geometry / resources ------------------------------------------------------------------------ */
+int raisr_hip_configure(raisr_hip_ctx *ctx, const raisr_hip_config *cfg);
+
+/* Hot path ------------------------------------------------------------------------------------
+ * Device-resident planes.  Pitches are in BYTES.  `stream` is a hipStream_t (NULL = the
+ * context's own stream).  Asynchronous: returns after enqueueing. */
+int raisr_hip_process_y_device(raisr_hip_ctx *ctx, const void *d_in, size_t in_pitch,
+                               void *d_out, size_t out_pitch, void *stream);
+/* cheap upscale of one plane (chroma path of RNLProcess): src/dst sample type from `bits` */
+int raisr_hip_resize_plane_device(raisr_hip_ctx *ctx, const void *d_src, int sw, int sh, size_t spitch,
+                                  void *d_dst, int dw, int dh, size_t dpitch, int bits, void *stream);
+/* Host planes in, host planes out (what RNLProcess hands over): stages through pinned memory,
+ * runs Y + both chroma planes, synchronous.  Chroma pointers may be NULL to skip chroma. */
+int raisr_hip_process_host(raisr_hip_ctx *ctx,
+                           const void *in_y, size_t in_y_pitch, void *out_y, size_t out_y_pitch,
+                           const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
+                           const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
+                           int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h);
+int raisr_hip_synchronize(raisr_hip_ctx *ctx);
+
+/* Introspection for tests / profiling ---------------------------------------------------------
+ * Copies the last frame's per-pixel hash plane (u16: low byte = first hash or 0xFF, high byte =
+ * tail re-hash or 0xFF) and fp32 HR plane of pass `pass_index` to host buffers (either may be NULL). */
+int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint16_t *hash_out, float *hr_out);
+/* Per-kernel HIP-event timing of subsequent process calls: events are recorded around every kernel on
+ * the stream it is launched on.  _read() returns the number of distinct kernels and fills, per kernel,
+ * its name (64 bytes each), the summed milliseconds and the launch count since _enable(ctx, 1);
+ * the caller synchronises first. */
+int raisr_hip_kernel_timing_enable(raisr_hip_ctx *ctx, int on);
+int raisr_hip_kernel_timing_read(raisr_hip_ctx *ctx, char *names_out, float *total_ms_out, int *count_out, int max_kernels);
+/* Times `iters` launches of each kernel of the configured pipeline on device-resident scratch
+ * input with HIP events on the context's stream; writes per-kernel average milliseconds.
+ * names_out receives up to max_kernels NUL-terminated names (64 bytes each). */
+int raisr_hip_profile_kernels(raisr_hip_ctx *ctx, const void *d_in, size_t in_pitch, void *d_out,
+                              size_t out_pitch, int iters, char *names_out, float *ms_out, int max_kernels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAISR_HIP_H */

@@ -1,0 +1,26 @@
+"""Shared helpers for the test-suite (paths, case matrix, frame factories)."""
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def folder(name):
+    return os.path.join(ROOT, name)
+
+
+def dtype_for(bits):
+    return np.uint8 if bits == 8 else np.uint16
+
+
+# (id, folder, ratio(num,den), bits, passes, mode, asm, full_range)
+CASES = [
+    ("2x_highres_8b_1p_avx512", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False),
+    ("2x_lowres_8b_1p_avx2", "filters_2x/filters_lowres", (2, 1), 8, 1, 1, 1, False),
+    ("2x_highres_8b_2p_m1", "filters_2x/filters_highres", (2, 1), 8, 2, 1, 2, False),
+    ("2x_denoise_8b_2p_m2", "filters_2x/filters_denoise", (2, 1), 8, 2, 2, 2, False),
+    ("2x_highres_10b_1p", "filters_2x/filters_highres", (2, 1), 10, 1, 1, 2, False),
+    ("2x_highres_8b_full", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, True),
+    ("1.5x_highres_8b_1p", "filters_1.5x/filters_highres", (3, 2), 8, 1, 1, 2, False),
+    ("1.5x_denoise_8b_2p_m2", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 2, False),
+]

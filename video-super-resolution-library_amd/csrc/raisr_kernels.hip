@@ -1,0 +1,932 @@
+// raisr_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the Enhanced-RAISR Y-plane hot path
+// and the C ABI declared in include/raisr_hip.h.
+//
+// Pipeline per RAISR pass (whole-frame semantics of the reference's processSegment(),
+// Library/Raisr.cpp:890-1289, run with threadcount=1):
+//
+//   k_resize   cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)      in  -> LR (u16)
+//   k_hash     11x11 structure tensor + hash  (Raisr_AVX512.cpp:69-131,175-258;
+//              tail columns also Raisr_AVX256.cpp:393-472)                          LR  -> hash (u16)
+//   k_filter   hash-indexed 121-tap filter + accept test (Raisr_AVX512.cpp:134-149,
+//              Raisr.cpp:1196-1200)                                                 LR,hash -> HR (f32)
+//   k_blend    census-transform blend, clamp, narrow, borders
+//              (Raisr_AVX256.cpp:68-166, Raisr.cpp:999-1028,1252-1265)              LR,HR -> out
+//
+// Numeric contract: every floating-point operation below maps to exactly one IEEE-754 binary32
+// operation of the cited reference lines ("strict source" semantics).  This file MUST be built
+// with -ffp-contract=off and without fast-math; FMAs appear only where the reference has an
+// explicit fmadd intrinsic.
+//
+// Design notes (MI355X): the work is fp32-VALU bound (~1 kFLOP per output pixel per pass against
+// ~1.25 compulsory HBM bytes), so the kernels are organised around VALU/LDS efficiency:
+//   * k_hash: one wave = 64 adjacent columns x R rows; gradients are computed once per tile into
+//     LDS as (gx,gy) float2 so the inner loop is ds_read_b64 + v_pk_mul_f32 + v_pk_fma_f32 +
+//     v_fmac_f32 per (pixel, tap) with the Gaussian weight in an SGPR; column accumulators are
+//     folded in the reference's reduction-tree order as they complete.
+//   * k_filter: 16 lanes per pixel (one lane per accumulator lane of the reference's zmm), so a
+//     filter row is fetched as fully coalesced 64-byte segments and the 16->1 tree is four DPP
+//     row rotations -- exactly the reference's sumitup_ps_512 association.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "../../include/raisr_hip.h"
+#include "x86_approx_tables.h"
+#include "x86_approx_dev.h"
+
+#if defined(__FAST_MATH__)
+#error "raisr_kernels.hip must be compiled without fast-math"
+#endif
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kTaps = 121;
+constexpr int kTapsPad = 128;
+constexpr int kMargin = 6;       // gLoopMargin, Raisr.cpp:1574
+constexpr int kBlobHeader = 64;  // bytes
+
+struct GaussW {
+    float wT[11][12];            // wT[k][i] = weight of patch row i, column k (column-major for the k-outer loop)
+};
+
+struct PassParams {
+    int W, H;                    // plane size of this pass
+    int lr_pitch;                // LR plane pitch in u16 elements
+    int hash_pitch;              // hash plane pitch in u16 elements
+    int hr_pitch;                // HR plane pitch in floats
+    float lo, hi;                // accept-test / clamp limits as float
+    int ilo, ihi;
+    int a_begin, a_end;          // columns hashed with the AVX-512 flavour
+    int b_begin, b_end;          // columns hashed with the AVX2 flavour (after the AVX-512 one)
+    int c_final;                 // first column that is never filtered
+    int pixel_types;             // 4 (ratio 2) or 1
+    float qangle, qs0, qs1, qc0, qc1;
+    const float* bank;           // [hash][type][128]
+    const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
+    const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_resize: centre-aligned bilinear with replicate border in exact integer arithmetic.
+// dst(y,x): n = (2d+1)*S - D, den = 2D per axis (reduced by gcd on the host: Sx,Dx,Sy,Dy).
+// ------------------------------------------------------------------------------------------------
+struct ResizeParams {
+    int sw, sh, dw, dh;
+    int spitch, dpitch;          // in elements
+    int Sx, Dx, Sy, Dy;          // reduced ratios
+    int tie_even;
+};
+
+__device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0, int& i1, int& f)
+{
+    const int n = (2 * d + 1) * S - D, den = 2 * D;
+    int q = n >= 0 ? n / den : -((-n + den - 1) / den);
+    f = n - q * den;
+    i0 = min(max(q, 0), size - 1);
+    i1 = min(max(q + 1, 0), size - 1);
+}
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= R.dw || y >= R.dh) return;
+    int x0, x1, fx, y0, y1, fy;
+    axis_tap(x, R.Sx, R.Dx, R.sw, x0, x1, fx);
+    axis_tap(y, R.Sy, R.Dy, R.sh, y0, y1, fy);
+    const long long denx = 2 * R.Dx, deny = 2 * R.Dy;
+    const TIn* r0 = src + (size_t)y0 * R.spitch;
+    const TIn* r1 = src + (size_t)y1 * R.spitch;
+    const long long top = (denx - fx) * (long long)r0[x0] + (long long)fx * r0[x1];
+    const long long bot = (denx - fx) * (long long)r1[x0] + (long long)fx * r1[x1];
+    const long long num = (deny - fy) * top + fy * bot;
+    const long long den = denx * deny;
+    long long q = (2 * num + den) / (2 * den);
+    if (R.tie_even && ((2 * num + den) % (2 * den) == 0) && (q & 1)) q--;
+    dst[(size_t)y * R.dpitch + x] = (TOut)q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
+// (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
+// ------------------------------------------------------------------------------------------------
+template <bool LEGACY>
+__device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut)
+{
+    if (LEGACY) return x86dev::rcp_legacy(x86dev::rsqrt_legacy(v, lut + 2048), lut);
+    return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+}
+
+template <bool LEGACY>
+__device__ __forceinline__ int hash_px(float a, float b, float d, const PassParams& P, const uint2* tab)
+{
+    const float pi = 3.141592653f;                       // Raisr_globals.h:29
+    const float T = a + d;
+    const float Dt = (a * d) - (b * b);
+    const float rad = ((T * T) * 0.25f) - Dt;            // x/4 == x*0.25 exactly
+    const float s = sqrt_approx<LEGACY>(rad, tab, P.lut_legacy);
+    const float hT = T * 0.5f;                           // T/2
+    const float L1 = hT + s;
+    const float L2 = hT - s;
+    const float xx = (b < 0.0f || b > 0.0f) ? (L1 - d) : 1.0f;   // _CMP_NEQ_OQ
+    // atan2Approximation (Raisr_AVX512.cpp:151-173)
+    const float ONEQTR_PI = (float)(3.14159265358979323846 / 4.0);          // (float)(M_PI/4.0)
+    const float THRQTR_PI = (float)(3.0 * 3.14159265358979323846 / 4.0);    // (float)(3.0*M_PI/4.0)
+    const float ay = __builtin_fabsf(b) + 1e-10f;
+    const float r1 = (xx + ay) / (ay - xx);
+    const float r2 = (xx - ay) / (xx + ay);
+    const bool neg = xx < 0.0f;
+    const float rr = neg ? r1 : r2;
+    float ang = neg ? THRQTR_PI : ONEQTR_PI;
+    ang = __builtin_fmaf(__builtin_fmaf(0.1963f * rr, rr, -0.9817f), rr, ang);
+    const float nang = -1.0f * ang;
+    ang = (b < 0.0f) ? nang : ang;
+    ang = ang + ((ang < 0.0f) ? pi : 0.0f);
+    const float sL1 = sqrt_approx<LEGACY>(L1, tab, P.lut_legacy);
+    const float sL2 = sqrt_approx<LEGACY>(L2, tab, P.lut_legacy);
+    const float coh = (sL1 - sL2) / ((sL1 + sL2) + 1e-17f);
+    const float str = L1;
+    const float fl = __builtin_floorf(ang * P.qangle);
+    int ai = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;   // cvtps_epi32
+    ai = min(23, max(ai, 0));
+    int si, ci;
+    if (!LEGACY) {
+        si = (int)(P.qs0 <= str) + (int)(P.qs1 <= str);
+        ci = (int)(P.qc0 <= coh) + (int)(P.qc1 <= coh);
+    } else {
+        si = 2 - ((int)(str <= P.qs0) + (int)(str <= P.qs1));
+        ci = 2 - ((int)(coh <= P.qc0) + (int)(coh <= P.qc1));
+    }
+    return ai * 9 + si * 3 + ci;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash: structure tensor + hash.  Block = 256 threads = 4 waves; tile = 64 columns x 4R rows of
+// the filtered zone [6,H-6) x [6,c_final); wave w owns rows [wR, wR+R), lane = column.
+// Column accumulators S_k (k = patch column) are built sequentially over the 11 patch rows
+// (computeGTWG_Segment_AVX512_32f, Raisr_AVX512.cpp:96-121) and folded in the association of
+// sumitup_ps_512 (:37-44): sum = ((S1+S9)+S5 + (S7+S3)) + (((S0+S8)+S4) + ((S2+S10)+S6)).
+// (The even/odd-pixel lane placements of the reference give the same value: they only commute
+// operands of individual additions.)
+// ------------------------------------------------------------------------------------------------
+__constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
+
+template <int R>
+__global__ __launch_bounds__(256, 4) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
+                                                  uint16_t* __restrict__ hash_out)
+{
+    constexpr int TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;    // LR tile incl. 6-px halo
+    constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[GH * GW_];
+    __shared__ uint2 sTab[128];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = kMargin + blockIdx.x * 64, r0 = kMargin + blockIdx.y * TH;
+
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1);
+        for (int tx = lane; tx < LW; tx += 64) {
+            const int gx = min(max(c0 - 6 + tx, 0), P.W - 1);
+            sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
+        }
+    }
+    __syncthreads();
+    // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+    for (int ty = w; ty < GH; ty += 4)
+        for (int tx = lane; tx < GW_; tx += 64) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
+            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+        }
+    __syncthreads();
+
+    f2 curAD[R], holdAD[R], t1AD[R];
+    float curB[R], holdB[R], t1B[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        curAD[j] = holdAD[j] = t1AD[j] = (f2){0.f, 0.f};
+        curB[j] = holdB[j] = t1B[j] = 0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < 11; kk++) {
+        const int k = c_col_order[kk];
+        f2 g[R + 10];
+#pragma unroll
+        for (int t = 0; t < R + 10; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
+        f2 AD[R];
+        float B[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) { AD[j] = (f2){0.f, 0.f}; B[j] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float wv = gw.wT[k][i];
+            const f2 w2 = {wv, wv};
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const f2 gg = g[i + j];
+                const f2 pq = gg * w2;                                   // (gx*w, gy*w)
+                AD[j] = __builtin_elementwise_fma(pq, gg, AD[j]);        // A += (gx*w)*gx ; D += (gy*w)*gy
+                B[j] = __builtin_fmaf(pq.x, gg.y, B[j]);                 // B += (gx*w)*gy
+            }
+        }
+        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
+        if (start) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = AD[j]; curB[j] = B[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = curAD[j] + AD[j]; curB[j] = curB[j] + B[j]; }
+        }
+        if (kk == 2 || kk == 8) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { holdAD[j] = curAD[j]; holdB[j] = curB[j]; }
+        }
+        if (kk == 5) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { t1AD[j] = holdAD[j] + curAD[j]; t1B[j] = holdB[j] + curB[j]; }
+        }
+    }
+
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        const f2 ad = (holdAD[j] + curAD[j]) + t1AD[j];      // (Gb+Gc) + (Ga+Gd)
+        const float bb = (holdB[j] + curB[j]) + t1B[j];
+        if (r < P.H - kMargin && c < P.c_final) {
+            unsigned hA = 0xFFu, hB = 0xFFu;
+            if (c >= P.a_begin && c < P.a_end) hA = (unsigned)hash_px<false>(ad.x, bb, ad.y, P, sTab);
+            if (c >= P.b_begin && c < P.b_end) hB = (unsigned)hash_px<true>(ad.x, bb, ad.y, P, sTab);
+            hash_out[(size_t)r * P.hash_pitch + c] = (uint16_t)(hA | (hB << 8));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_filter: HR = (lo < v < hi) ? v : LR with v = DotProdPatch(patch, bank[hash][type])
+// (Raisr_AVX512.cpp:134-149; accept test Raisr.cpp:1196-1200).  16 lanes per pixel: lane l owns the
+// reference's zmm lane l: acc = p[l]*f[l]; acc = fma(p[16c+l], f[16c+l], acc) for c=1..7;
+// then sumitup_ps_512 as DPP row rotations by 8, 4, 2, 1.
+// Tile = 64 columns x 16 rows; wave w owns tile rows [4w, 4w+4); each step handles 4 adjacent pixels.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float tree16(float acc)
+{
+    acc = acc + row_ror<0x128>(acc);    // row_ror:8  -> r8[i] = a[i] + a[i+8]
+    acc = acc + row_ror<0x124>(acc);    // row_ror:4  -> r4[i] = r8[i] + r8[i+4]
+    acc = acc + row_ror<0x122>(acc);    // row_ror:2  -> r2[i] = r4[i] + r4[i+2]
+    acc = acc + row_ror<0x121>(acc);    // row_ror:1  -> r2[0] + r2[1]
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hash,
+                                                PassParams P, float* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 10, LH = TH + 10;
+    __shared__ float sL[LH * LW];
+    __shared__ uint16_t sH[TH * TW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, l = lane & 15;
+    const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
+
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
+        for (int tx = lane; tx < LW; tx += 64) {
+            const int gx = min(max(c0 - 5 + tx, 0), P.W - 1);
+            sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
+        }
+    }
+    for (int ty = w; ty < TH; ty += 4) {
+        const int r = r0 + ty, c = c0 + lane;
+        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint16_t)0xFFFFu;
+    }
+    __syncthreads();
+
+    int off[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) {
+        const int k = 16 * ch + l;
+        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : -1;
+    }
+
+#pragma unroll 1
+    for (int row = 0; row < 4; row++) {
+        const int prow = 4 * w + row;
+        const int r = r0 + prow;
+        float keep = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < 16; s++) {
+            const int pcol = 4 * s + g;
+            const int c = c0 + pcol;
+            const unsigned hh = sH[prow * TW + pcol];
+            const unsigned hA = hh & 0xFFu, hB = hh >> 8;
+            const int base = prow * LW + pcol;                  // patch top-left in the tile
+            const float center = sL[base + 5 * LW + 5];
+            const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
+            float p[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) p[ch] = (off[ch] >= 0) ? sL[base + off[ch]] : 0.0f;
+            float res = center;
+            if (hA != 0xFFu) {
+                const float* f = P.bank + ((size_t)(hA * P.pixel_types + t) * kTapsPad + l);
+                float acc = p[0] * f[0];
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(p[ch], f[16 * ch], acc);
+                const float v = tree16(acc);
+                if (v > P.lo && v < P.hi) res = v;
+            }
+            if (hB != 0xFFu) {                                  // tail columns: AVX2 re-hash, keep-first-if-rejected
+                const float* f = P.bank + ((size_t)(hB * P.pixel_types + t) * kTapsPad + l);
+                float acc = p[0] * f[0];
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(p[ch], f[16 * ch], acc);
+                const float v = tree16(acc);
+                if (v > P.lo && v < P.hi) res = v;
+            }
+            if (s == l) keep = res;                             // lane (g,l) keeps pixel column 4l+g
+        }
+        const int c = c0 + 4 * l + g;
+        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blend (CountOfBitsChanged): CTCountOfBitsChangedSegment_AVX256_32f, Raisr_AVX256.cpp:68-166,
+// plus the border policy of processSegment (Raisr.cpp:999-1028,1252-1265): row 0, row H-1, col 0,
+// col W-1 keep the unclamped LR value.
+// ------------------------------------------------------------------------------------------------
+template <typename TOut>
+__global__ __launch_bounds__(256) void k_blend(const uint16_t* __restrict__ lr, const float* __restrict__ hr,
+                                               PassParams P, TOut* __restrict__ out, int out_pitch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    const uint16_t lc = lr[(size_t)y * P.lr_pitch + x];
+    if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
+        out[(size_t)y * out_pitch + x] = (TOut)lc;
+        return;
+    }
+    const float Lc = (float)lc;
+    auto inzone = [&](int yy, int xx) { return yy >= kMargin && yy < P.H - kMargin && xx >= kMargin && xx < P.c_final; };
+    const float Hc = inzone(y, x) ? hr[(size_t)y * P.hr_pitch + x] : Lc;
+    int hd = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            const float Ln = (float)lr[(size_t)(y + dy) * P.lr_pitch + x + dx];
+            const float Hn = inzone(y + dy, x + dx) ? hr[(size_t)(y + dy) * P.hr_pitch + x + dx] : Ln;
+            const int bl = Ln < Lc, bh = Hn < Hc;
+            hd += (bl != bh);
+        }
+    const float weight = (float)hd * 0.125f;                   // hd / 8.0f exactly
+    const float w2 = 1.0f - weight;
+    float val = (weight * Lc) + (w2 * Hc);
+    val = val + 0.5f;
+    const float fl = __builtin_floorf(val);
+    int iv = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
+    iv = max(min(iv, P.ihi), P.ilo);
+    out[(size_t)y * out_pitch + x] = (TOut)iv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    g_err = what;
+    if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) return fail(RAISR_HIP_ERUNTIME, #expr, _e);      \
+    } while (0)
+
+struct BlobHeader {
+    uint32_t magic;
+    int32_t hashkeys, pixel_types, quant_angle;
+    float qangle, qstr[2], qcoh[2];
+    uint32_t pad[7];
+};
+static_assert(sizeof(BlobHeader) == kBlobHeader, "blob header size");
+constexpr uint32_t kBlobMagic = 0x52534152u;   // "RASR"
+
+struct ModelDev {
+    void* blob = nullptr;
+    size_t bytes = 0;
+    BlobHeader h{};
+    bool valid = false;
+};
+
+struct KernelTimer {
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<std::string> names;
+    bool enabled = false;
+    size_t cap = 8192;
+};
+
+int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// Gaussian weights: gGaussian2D{8,10,16}bit (Raisr_globals.h:208-264) = (float)((double)NF * literal);
+// the literal table is symmetric, Q is its upper-left quadrant.
+const double kGaussQ[6][6] = {
+    {7.76554e-05, 0.000239195, 0.0005738, 0.001072, 0.00155975, 0.00176743},
+    {0.000239195, 0.000736774, 0.00176743, 0.00330199, 0.00480437, 0.00544406},
+    {0.0005738, 0.00176743, 0.00423984, 0.00792107, 0.0115251, 0.0130596},
+    {0.001072, 0.00330199, 0.00792107, 0.0147985, 0.0215317, 0.0243986},
+    {0.00155975, 0.00480437, 0.0115251, 0.0215317, 0.0313284, 0.0354998},
+    {0.00176743, 0.00544406, 0.0130596, 0.0243986, 0.0354998, 0.0402265},
+};
+
+GaussW make_gauss(int bits)
+{
+    GaussW g{};
+    const float maxv = bits == 8 ? 255.0f : (bits == 10 ? 1023.0f : 65535.0f);
+    volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
+    for (int i = 0; i < 11; i++)
+        for (int k = 0; k < 11; k++) {
+            const int qi = i < 6 ? i : 10 - i, qk = k < 6 ? k : 10 - k;
+            g.wT[k][i] = (float)((double)nf * kGaussQ[qi][qk]);
+        }
+    return g;
+}
+
+// Column plan of the reference's chunk driver (Raisr.cpp:1065-1066,1246-1250).
+void column_plan(int W, int hash_variant, PassParams& P)
+{
+    const int unroll = hash_variant == RAISR_HIP_HASH_AVX512 ? 16 : 8;
+    int loopItr = unroll, c = kMargin;
+    P.a_begin = P.a_end = P.b_begin = P.b_end = kMargin;
+    bool a_any = false, b_any = false;
+    while (c + loopItr <= W - kMargin) {
+        if (loopItr == 16) { if (!a_any) { P.a_begin = c; a_any = true; } P.a_end = c + 16; }
+        else { if (!b_any) { P.b_begin = c; b_any = true; } P.b_end = c + 8; }
+        if (loopItr > 8 && c + 2 * unroll > W - kMargin) loopItr = 8;
+        c += loopItr;
+    }
+    P.c_final = a_any || b_any ? (b_any ? P.b_end : P.a_end) : kMargin;
+    if (a_any && b_any && P.a_end > P.b_end) P.c_final = P.a_end;
+}
+
+}  // namespace
+
+struct raisr_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    raisr_hip_config cfg{};
+    bool configured = false;
+    ModelDev model[2];
+    // shared small tables
+    uint2* d_tab14 = nullptr;
+    uint16_t* d_lut = nullptr;
+    // scratch planes
+    uint16_t* d_lr[2] = {nullptr, nullptr};     // LR plane per pass (u16)
+    uint16_t* d_hash[2] = {nullptr, nullptr};
+    float* d_hr[2] = {nullptr, nullptr};
+    uint16_t* d_mid = nullptr;                  // two-pass intermediate (u16)
+    int passW[2] = {0, 0}, passH[2] = {0, 0};
+    GaussW gauss{};
+    // host staging for raisr_hip_process_host
+    void* h_pin = nullptr; size_t h_pin_bytes = 0;
+    void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    KernelTimer timer;
+};
+
+namespace {
+
+void timer_begin(raisr_hip_ctx* c, const char* name, hipStream_t s, int& slot)
+{
+    slot = -1;
+    KernelTimer& T = c->timer;
+    if (!T.enabled || T.recs.size() >= T.cap) return;
+    int id = -1;
+    for (size_t i = 0; i < T.names.size(); i++) if (T.names[i] == name) { id = (int)i; break; }
+    if (id < 0) { T.names.push_back(name); id = (int)T.names.size() - 1; }
+    KernelTimer::Rec r{id, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    T.recs.push_back(r);
+    slot = (int)T.recs.size() - 1;
+}
+void timer_end(raisr_hip_ctx* c, hipStream_t s, int slot)
+{
+    if (slot >= 0) (void)hipEventRecord(c->timer.recs[slot].b, s);
+}
+
+ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch, int tie)
+{
+    ResizeParams R{};
+    R.sw = sw; R.sh = sh; R.dw = dw; R.dh = dh; R.spitch = spitch; R.dpitch = dpitch;
+    const int gx = gcd_int(sw, dw), gy = gcd_int(sh, dh);
+    R.Sx = sw / gx; R.Dx = dw / gx; R.Sy = sh / gy; R.Dy = dh / gy;
+    R.tie_even = tie == RAISR_HIP_TIE_HALF_EVEN;
+    return R;
+}
+
+template <typename TIn, typename TOut>
+void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, const ResizeParams& R, const char* name)
+{
+    dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+    int slot;
+    timer_begin(c, name, s, slot);
+    hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    timer_end(c, s, slot);
+}
+
+PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
+{
+    PassParams P{};
+    const raisr_hip_config& g = c->cfg;
+    const ModelDev& m = c->model[pass];
+    P.W = W; P.H = H;
+    P.lr_pitch = W; P.hash_pitch = W; P.hr_pitch = W;
+    P.lo = (float)g.clamp_lo; P.hi = (float)g.clamp_hi;
+    P.ilo = g.clamp_lo; P.ihi = g.clamp_hi;
+    column_plan(W, g.hash_variant, P);
+    P.pixel_types = m.h.pixel_types;
+    P.qangle = m.h.qangle;
+    P.qs0 = m.h.qstr[0]; P.qs1 = m.h.qstr[1];
+    P.qc0 = m.h.qcoh[0]; P.qc1 = m.h.qcoh[1];
+    P.bank = (const float*)((const char*)m.blob + kBlobHeader);
+    P.tab14 = c->d_tab14;
+    P.lut_legacy = c->d_lut;
+    return P;
+}
+
+// one RAISR pass on an LR plane already resident in c->d_lr[pass]
+template <typename TOut>
+void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+{
+    const int W = c->passW[pass], H = c->passH[pass];
+    PassParams P = make_pass(c, pass, W, H);
+    int slot;
+    if (P.c_final > kMargin && H > 2 * kMargin) {
+        constexpr int R = 4;
+        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
+        timer_begin(c, "k_hash", s, slot);
+        hipLaunchKernelGGL((k_hash<R>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
+        timer_end(c, s, slot);
+        dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
+        timer_begin(c, "k_filter", s, slot);
+        hipLaunchKernelGGL(k_filter, gf, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, c->d_hr[pass]);
+        timer_end(c, s, slot);
+    }
+    dim3 gb((W + 63) / 64, (H + 3) / 4);
+    timer_begin(c, "k_blend", s, slot);
+    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
+}
+
+void free_scratch(raisr_hip_ctx* c)
+{
+    for (int i = 0; i < 2; i++) {
+        if (c->d_lr[i]) (void)hipFree(c->d_lr[i]);
+        if (c->d_hash[i]) (void)hipFree(c->d_hash[i]);
+        if (c->d_hr[i]) (void)hipFree(c->d_hr[i]);
+        c->d_lr[i] = nullptr; c->d_hash[i] = nullptr; c->d_hr[i] = nullptr;
+    }
+    if (c->d_mid) (void)hipFree(c->d_mid);
+    c->d_mid = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* raisr_hip_last_error(void) { return g_err.c_str(); }
+const char* raisr_hip_version(void) { return "raisr-hip 0.1 (gfx950)"; }
+
+int raisr_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int raisr_hip_create(raisr_hip_ctx** out, int device_index)
+{
+    if (!out) return fail(RAISR_HIP_EINVAL, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RAISR_HIP_ENODEV, "no HIP device visible", e);
+    if (device_index < 0 || device_index >= n) return fail(RAISR_HIP_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device_index));
+    raisr_hip_ctx* c = new raisr_hip_ctx();
+    c->device = device_index;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // small shared tables
+    std::vector<uint2> tab(128);
+    for (int i = 0; i < 64; i++) { tab[i] = make_uint2(X86_RCP14_C0[i], X86_RCP14_C1[i]); tab[64 + i] = make_uint2(X86_RSQRT14_C0[i], X86_RSQRT14_C1[i]); }
+    std::vector<uint16_t> lut(4096);
+    for (int i = 0; i < 2048; i++) { lut[i] = X86_RCP_LUT[i]; lut[2048 + i] = X86_RSQRT_LUT[i]; }
+    HIP_TRY(hipMalloc((void**)&c->d_tab14, tab.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void**)&c->d_lut, lut.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(c->d_tab14, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *out = c;
+    return RAISR_HIP_OK;
+}
+
+void raisr_hip_destroy(raisr_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->timer.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    free_scratch(c);
+    for (int i = 0; i < 2; i++) if (c->model[i].blob) hipFree(c->model[i].blob);
+    if (c->d_tab14) (void)hipFree(c->d_tab14);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t raisr_hip_model_blob_bytes(int hashkeys, int pixel_types)
+{
+    if (hashkeys <= 0 || pixel_types <= 0) return 0;
+    return (size_t)kBlobHeader + (size_t)hashkeys * pixel_types * kTapsPad * sizeof(float);
+}
+
+int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, int pixel_types,
+                              const float qstr[2], const float qcoh[2], int quant_angle)
+{
+    if (!host_blob || !bank || !qstr || !qcoh) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (hashkeys <= 0 || hashkeys > 255 || (pixel_types != 1 && pixel_types != 4) || quant_angle <= 0)
+        return fail(RAISR_HIP_EINVAL, "unsupported model geometry");
+    BlobHeader h{};
+    h.magic = kBlobMagic; h.hashkeys = hashkeys; h.pixel_types = pixel_types; h.quant_angle = quant_angle;
+    h.qangle = (float)quant_angle / 3.141592653f;           // gQAngle, Raisr.cpp:1553
+    h.qstr[0] = qstr[0]; h.qstr[1] = qstr[1]; h.qcoh[0] = qcoh[0]; h.qcoh[1] = qcoh[1];
+    memcpy(host_blob, &h, sizeof h);
+    float* dst = (float*)((char*)host_blob + kBlobHeader);
+    const size_t rows = (size_t)hashkeys * pixel_types;
+    memset(dst, 0, rows * kTapsPad * sizeof(float));
+    for (size_t r = 0; r < rows; r++) memcpy(dst + r * kTapsPad, bank + r * kTaps, kTaps * sizeof(float));
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void* device_blob, size_t bytes, void* stream)
+{
+    if (!c || !device_blob || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    BlobHeader h{};
+    HIP_TRY(hipMemcpyAsync(&h, device_blob, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h.magic != kBlobMagic || raisr_hip_model_blob_bytes(h.hashkeys, h.pixel_types) != bytes)
+        return fail(RAISR_HIP_EINVAL, "model blob corrupted");
+    ModelDev& m = c->model[pass_index];
+    if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
+    if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
+    HIP_TRY(hipMemcpyAsync(m.blob, device_blob, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m.bytes = bytes; m.h = h; m.valid = true;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,
+                        const float qstr[2], const float qcoh[2], int quant_angle)
+{
+    if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    const size_t bytes = raisr_hip_model_blob_bytes(hashkeys, pixel_types);
+    if (!bytes) return fail(RAISR_HIP_EINVAL, "bad model geometry");
+    std::vector<char> host(bytes);
+    int rc = raisr_hip_pack_model_blob(host.data(), bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    ModelDev& m = c->model[pass_index];
+    if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
+    if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
+    HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
+    m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
+{
+    if (!c || !cfg) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (cfg->bits != 8 && cfg->bits != 10 && cfg->bits != 16) return fail(RAISR_HIP_EINVAL, "bits must be 8, 10 or 16");
+    if (cfg->passes != 1 && cfg->passes != 2) return fail(RAISR_HIP_EINVAL, "passes must be 1 or 2");
+    if (cfg->in_width <= 0 || cfg->in_height <= 0 || cfg->out_width <= 0 || cfg->out_height <= 0)
+        return fail(RAISR_HIP_EINVAL, "bad plane size");
+    if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512)
+        return fail(RAISR_HIP_EINVAL, "hash variant not supported by this build");
+    if (cfg->blending != RAISR_HIP_BLEND_COUNT) return fail(RAISR_HIP_EINVAL, "blending mode not supported by this build");
+    if (!c->model[0].valid || (cfg->passes == 2 && !c->model[1].valid)) return fail(RAISR_HIP_ESTATE, "model not set");
+    for (int p = 0; p < cfg->passes; p++)
+        if (c->model[p].h.pixel_types != (cfg->use_pixel_type ? 4 : 1))
+            return fail(RAISR_HIP_EINVAL, "model pixel types do not match ratio");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_scratch(c);
+    c->cfg = *cfg;
+    c->gauss = make_gauss(cfg->bits);
+    const bool mode2 = cfg->passes == 2 && cfg->two_pass_mode == 2;
+    c->passW[0] = mode2 ? cfg->in_width : cfg->out_width;
+    c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
+    c->passW[1] = cfg->out_width; c->passH[1] = cfg->out_height;
+    for (int p = 0; p < cfg->passes; p++) {
+        const size_t n = (size_t)c->passW[p] * c->passH[p];
+        if (hipMalloc((void**)&c->d_lr[p], n * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash[p], n * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc((void**)&c->d_hr[p], n * sizeof(float)) != hipSuccess) {
+            free_scratch(c);
+            return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
+        }
+    }
+    if (cfg->passes == 2) {
+        const size_t n = (size_t)c->passW[0] * c->passH[0];
+        if (hipMalloc((void**)&c->d_mid, n * sizeof(uint16_t)) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
+    }
+    c->configured = true;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream)
+{
+    if (!c || !d_in || !d_out) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const raisr_hip_config& g = c->cfg;
+    const int bps = g.bits == 8 ? 1 : 2;
+    if (in_pitch % bps || out_pitch % bps) return fail(RAISR_HIP_EINVAL, "pitch not a multiple of the sample size");
+    const int ipe = (int)(in_pitch / bps), ope = (int)(out_pitch / bps);
+
+    // pass-1 LR: cheap upscale of the input (or an identity widen when pass 1 runs at input size)
+    {
+        ResizeParams R = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
+        if (bps == 1) launch_resize<uint8_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
+        else launch_resize<uint16_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
+    }
+    if (g.passes == 1) {
+        if (bps == 1) run_pass<uint8_t>(c, s, 0, d_out, ope); else run_pass<uint16_t>(c, s, 0, d_out, ope);
+    } else {
+        run_pass<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
+        // pass-2 LR: the intermediate, upscaled now if mode 2 (Raisr.cpp:945-975)
+        ResizeParams R = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
+        launch_resize<uint16_t, uint16_t>(c, s, c->d_mid, c->d_lr[1], R, "k_resize");
+        if (bps == 1) run_pass<uint8_t>(c, s, 1, d_out, ope); else run_pass<uint16_t>(c, s, 1, d_out, ope);
+    }
+    HIP_TRY(hipGetLastError());
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_resize_plane_device(raisr_hip_ctx* c, const void* d_src, int sw, int sh, size_t spitch,
+                                  void* d_dst, int dw, int dh, size_t dpitch, int bits, void* stream)
+{
+    if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int bps = bits == 8 ? 1 : 2;
+    ResizeParams R = make_resize(sw, sh, (int)(spitch / bps), dw, dh, (int)(dpitch / bps), c->configured ? c->cfg.tie_rule : 0);
+    if (bps == 1) launch_resize<uint8_t, uint8_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
+    else launch_resize<uint16_t, uint16_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
+    HIP_TRY(hipGetLastError());
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_synchronize(raisr_hip_ctx* c)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_process_host(raisr_hip_ctx* c,
+                           const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
+                           const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
+                           const void* in_v, size_t in_v_pitch, void* out_v, size_t out_v_pitch,
+                           int cin_w, int cin_h, int cout_w, int cout_h)
+{
+    if (!c || !in_y || !out_y) return fail(RAISR_HIP_EINVAL, "null plane");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    HIP_TRY(hipSetDevice(c->device));
+    const raisr_hip_config& g = c->cfg;
+    const int bps = g.bits == 8 ? 1 : 2;
+    const bool chroma = in_u && out_u && in_v && out_v && cin_w > 0 && cin_h > 0 && cout_w > 0 && cout_h > 0;
+    // tightly packed device staging: [inY][inU][inV][outY][outU][outV]
+    const size_t iy = (size_t)g.in_width * g.in_height * bps, oy = (size_t)g.out_width * g.out_height * bps;
+    const size_t ic = chroma ? (size_t)cin_w * cin_h * bps : 0, oc = chroma ? (size_t)cout_w * cout_h * bps : 0;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t off_iu = al(iy), off_iv = off_iu + al(ic), off_oy = off_iv + al(ic), off_ou = off_oy + al(oy), off_ov = off_ou + al(oc);
+    const size_t total = off_ov + al(oc);
+    if (c->d_stage_bytes < total) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->d_stage_bytes = 0;
+        if (hipMalloc(&c->d_stage, total) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "staging alloc");
+        c->d_stage_bytes = total;
+    }
+    char* d = (char*)c->d_stage;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpy2DAsync(d, (size_t)g.in_width * bps, in_y, in_y_pitch, (size_t)g.in_width * bps, g.in_height, hipMemcpyHostToDevice, s));
+    if (chroma) {
+        HIP_TRY(hipMemcpy2DAsync(d + off_iu, (size_t)cin_w * bps, in_u, in_u_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(d + off_iv, (size_t)cin_w * bps, in_v, in_v_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
+    }
+    int rc = raisr_hip_process_y_device(c, d, (size_t)g.in_width * bps, d + off_oy, (size_t)g.out_width * bps, s);
+    if (rc) return rc;
+    if (chroma) {
+        rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, (size_t)cin_w * bps, d + off_ou, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s);
+        if (rc) return rc;
+        rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, (size_t)cin_w * bps, d + off_ov, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy, (size_t)g.out_width * bps, (size_t)g.out_width * bps, g.out_height, hipMemcpyDeviceToHost, s));
+    if (chroma) {
+        HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint16_t* hash_out, float* hr_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (!c->configured || !c->d_hash[pass_index]) return fail(RAISR_HIP_ESTATE, "pass not configured");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = (size_t)c->passW[pass_index] * c->passH[pass_index];
+    if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (hr_out) HIP_TRY(hipMemcpy(hr_out, c->d_hr[pass_index], n * sizeof(float), hipMemcpyDeviceToHost));
+    return RAISR_HIP_OK;
+}
+
+// Enable/disable per-kernel HIP-event timing of subsequent process calls (events are recorded on the
+// stream each kernel is launched on).
+int raisr_hip_kernel_timing_enable(raisr_hip_ctx* c, int on)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    KernelTimer& T = c->timer;
+    for (auto& r : T.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    T.recs.clear(); T.names.clear();
+    T.enabled = on != 0;
+    return RAISR_HIP_OK;
+}
+
+// Collects the timings recorded since the last enable: per kernel name, total milliseconds and
+// launch count.  Caller must have synchronised the stream(s).  Returns the number of kernels.
+int raisr_hip_kernel_timing_read(raisr_hip_ctx* c, char* names_out, float* total_ms_out, int* count_out, int max_kernels)
+{
+    if (!c || !names_out || !total_ms_out || !count_out) return fail(RAISR_HIP_EINVAL, "null argument");
+    KernelTimer& T = c->timer;
+    const int n = (int)T.names.size() < max_kernels ? (int)T.names.size() : max_kernels;
+    for (int i = 0; i < n; i++) {
+        snprintf(names_out + 64 * i, 64, "%s", T.names[i].c_str());
+        total_ms_out[i] = 0.f; count_out[i] = 0;
+    }
+    for (auto& r : T.recs) {
+        if (r.id >= n) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms_out[r.id] += ms; count_out[r.id]++; }
+    }
+    return n;
+}
+
+int raisr_hip_profile_kernels(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch,
+                              int iters, char* names_out, float* ms_out, int max_kernels)
+{
+    if (!c || iters <= 0 || !names_out || !ms_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    int rc = raisr_hip_kernel_timing_enable(c, 1);
+    if (rc) return rc;
+    for (int i = 0; i < iters; i++) {
+        rc = raisr_hip_process_y_device(c, d_in, in_pitch, d_out, out_pitch, nullptr);
+        if (rc) return rc;
+    }
+    rc = raisr_hip_synchronize(c);
+    if (rc) return rc;
+    std::vector<int> counts(max_kernels);
+    int n = raisr_hip_kernel_timing_read(c, names_out, ms_out, counts.data(), max_kernels);
+    for (int i = 0; i < n; i++) if (counts[i]) ms_out[i] /= counts[i];
+    raisr_hip_kernel_timing_enable(c, 0);
+    return n;
+}
+
+}  // extern "C"

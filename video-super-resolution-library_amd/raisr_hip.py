@@ -1,0 +1,289 @@
+"""ctypes bindings of libraisr_hip.so -- the MI355X Enhanced-RAISR library.
+
+Two layers, both straight over the C ABI (no torch types cross the boundary):
+
+* `RNLHandler_*` -- the reference's plugin API (reference Library/RaisrHandler.h:15-48) exactly as
+  FFmpeg's vf_raisr calls it: host planes in, host planes out.  `upscale_frame_host()` is the
+  call protocol of vf_raisr.c:146,286-312 (Init once, SetRes on the first frame, Process per frame).
+* `RaisrDevice` -- the device-resident hot path (`raisr_hip_*`, include/raisr_hip.h) used by the
+  benchmark and the parity tests: planes live in HBM (e.g. torch tensors' data_ptr()), launches go
+  to a caller-supplied HIP stream.
+
+The extension is REQUIRED: importing succeeds without it, but any use raises RuntimeError -- there
+is no CPU fallback in the product.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libraisr_hip.so")
+_LIB = None
+
+# RaisrDefaults.h enums
+RNLErrorNone = 0
+RNLErrorInsufficientResources = ctypes.c_int(0x80001000 - (1 << 32)).value
+RNLErrorUndefined = ctypes.c_int(0x80001001 - (1 << 32)).value
+RNLErrorBadParameter = ctypes.c_int(0x80001002 - (1 << 32)).value
+Randomness, CountOfBitsChanged = 1, 2
+AVX2, AVX512, OpenCL, OpenCLExternal, AVX512_FP16, HIP = 1, 2, 3, 4, 5, 6
+VideoRange, FullRange = 1, 2
+
+HASH_AVX2, HASH_AVX512, HASH_FP16 = 1, 2, 5
+BLEND_RANDOMNESS, BLEND_COUNT = 1, 2
+TIE_HALF_UP, TIE_HALF_EVEN = 0, 1
+
+
+class VideoDataType(ctypes.Structure):
+    _fields_ = [("pData", ctypes.c_void_p), ("width", ctypes.c_uint), ("height", ctypes.c_uint),
+                ("step", ctypes.c_uint), ("bitShift", ctypes.c_uint)]
+
+
+class RaisrHipConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "in_width", "in_height", "out_width", "out_height", "bits", "clamp_lo", "clamp_hi", "passes",
+        "two_pass_mode", "hash_variant", "blending", "use_pixel_type", "tie_rule")]
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"{_SO} is missing: build it with `make -C {_HERE}` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        L = ctypes.CDLL(_SO)
+        L.raisr_hip_last_error.restype = ctypes.c_char_p
+        L.raisr_hip_version.restype = ctypes.c_char_p
+        L.raisr_hip_model_blob_bytes.restype = ctypes.c_size_t
+        L.raisr_hip_model_blob_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+        L.raisr_hip_destroy.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_destroy.restype = None
+        L.raisr_hip_set_model.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_pack_model_blob.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_set_model_blob_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.raisr_hip_configure.argtypes = [ctypes.c_void_p, ctypes.POINTER(RaisrHipConfig)]
+        L.raisr_hip_process_y_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                 ctypes.c_size_t, ctypes.c_void_p]
+        L.raisr_hip_resize_plane_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        L.raisr_hip_process_host.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
+        L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.RNLHandler_Init.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
+                                      ctypes.c_int, ctypes.c_uint, ctypes.c_uint]
+        vp = ctypes.POINTER(VideoDataType)
+        L.RNLHandler_SetRes.argtypes = [vp] * 6
+        L.RNLHandler_Process.argtypes = [vp] * 6 + [ctypes.c_int]
+        L.RNLHandler_SetOpenCLContext.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    return lib().raisr_hip_last_error().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def clamp_range(bits, full_range):
+    """gMin/gMax of RNLInit (reference Library/Raisr.cpp:1451-1468)."""
+    if bits == 8:
+        return (0, 255) if full_range else (16, 235)
+    if bits == 10:
+        return (0, 1023) if full_range else (64, 940)
+    return (0, 65535)
+
+
+# ----------------------------------------------------------------------------------------------
+# Reference plugin API (host planes)
+# ----------------------------------------------------------------------------------------------
+def RNLHandler_Init(model_path, ratio, bit_depth=8, range_type=VideoRange, thread_count=20, asm_type=AVX512,
+                    passes=1, two_pass_mode=1):
+    return lib().RNLHandler_Init(os.fsencode(model_path), ratio, bit_depth, range_type, thread_count, asm_type,
+                                 passes, two_pass_mode)
+
+
+def RNLHandler_SetOpenCLContext(platform_index=0, device_index=0):
+    return lib().RNLHandler_SetOpenCLContext(None, None, platform_index, device_index)
+
+
+def RNLHandler_Deinit():
+    return lib().RNLHandler_Deinit()
+
+
+def _vdt(a):
+    v = VideoDataType()
+    v.pData = a.ctypes.data
+    v.height, v.width = a.shape
+    v.step = a.strides[0]
+    v.bitShift = 0
+    return v
+
+
+def RNLHandler_SetRes(in_planes, out_planes):
+    d = [_vdt(p) for p in list(in_planes) + list(out_planes)]
+    return lib().RNLHandler_SetRes(*[ctypes.byref(x) for x in d])
+
+
+def RNLHandler_Process(in_planes, out_planes, blending=CountOfBitsChanged):
+    d = [_vdt(p) for p in list(in_planes) + list(out_planes)]
+    return lib().RNLHandler_Process(*[ctypes.byref(x) for x in d], blending)
+
+
+def upscale_frame_host(y, u, v, model_path, ratio=2.0, bits=8, range_type=VideoRange, asm_type=AVX512, passes=1,
+                       mode=1, blending=CountOfBitsChanged, device=0):
+    """One frame through the RNLHandler call protocol of vf_raisr.c.  Planes are 2-D numpy arrays
+    (uint8 for 8-bit, uint16 otherwise); returns (Y, U, V) output arrays."""
+    oh, ow = int(y.shape[0] * ratio), int(y.shape[1] * ratio)
+    och, ocw = int(u.shape[0] * ratio), int(u.shape[1] * ratio)
+    oy = np.zeros((oh, ow), y.dtype); ou = np.zeros((och, ocw), u.dtype); ov = np.zeros((och, ocw), v.dtype)
+    RNLHandler_SetOpenCLContext(0, device)
+    rc = RNLHandler_Init(model_path, ratio, bits, range_type, 20, asm_type, passes, mode)
+    if rc != RNLErrorNone:
+        raise RuntimeError(f"RNLHandler_Init rc={rc:#x}")
+    try:
+        rc = RNLHandler_SetRes((y, u, v), (oy, ou, ov))
+        if rc != RNLErrorNone:
+            raise RuntimeError(f"RNLHandler_SetRes rc={rc:#x}")
+        rc = RNLHandler_Process((y, u, v), (oy, ou, ov), blending)
+        if rc != RNLErrorNone:
+            raise RuntimeError(f"RNLHandler_Process rc={rc:#x}")
+    finally:
+        RNLHandler_Deinit()
+    return oy, ou, ov
+
+
+# ----------------------------------------------------------------------------------------------
+# Trained-data folder -> arrays (host-side helper for the device API; the C++ loader in
+# csrc/raisr_api.cpp is the one RNLHandler_Init uses)
+# ----------------------------------------------------------------------------------------------
+def read_model_folder(folder, bits, pass_no):
+    sfx = f"_2_{bits}" + ("_2" if pass_no == 2 else "")
+    raw = open(os.path.join(folder, "filterbin" + sfx), "rb").read()
+    if raw[:4] != b"fp32":
+        raise ValueError("hashtable corrupted")
+    hk, pt, rows = (int(t) for t in np.frombuffer(raw[4:16], dtype="<u4"))
+    if len(raw) - 16 != hk * pt * rows * 4 or rows != 121:
+        raise ValueError("hashtable corrupted")
+    bank = np.frombuffer(raw[16:], dtype="<f4").reshape(hk, pt, rows).copy()
+    qstr = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_strbin" + sfx)).read().split()], np.float32)
+    qcoh = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_cohbin" + sfx)).read().split()], np.float32)
+    qa = int(open(os.path.join(folder, "config")).readline().split()[0])
+    return bank, qstr, qcoh, qa
+
+
+def pack_model_blob(bank, qstr, qcoh, quant_angle):
+    """Device-layout model blob as a numpy uint8 array (what gets RCCL-broadcast between ranks)."""
+    hk, pt, _ = bank.shape
+    n = lib().raisr_hip_model_blob_bytes(hk, pt)
+    blob = np.zeros(n, np.uint8)
+    bank = np.ascontiguousarray(bank, np.float32)
+    qstr = np.ascontiguousarray(qstr, np.float32); qcoh = np.ascontiguousarray(qcoh, np.float32)
+    _check(lib().raisr_hip_pack_model_blob(blob.ctypes.data, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
+                                           quant_angle), "pack_model_blob")
+    return blob
+
+
+class RaisrDevice:
+    """One in-flight-frame lane of the device-resident hot path."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().raisr_hip_create(ctypes.byref(self._h), device), "raisr_hip_create")
+        self.cfg = None
+
+    def close(self):
+        if self._h:
+            lib().raisr_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_model_from_folder(self, folder, bits, passes=1):
+        for p in range(passes):
+            bank, qstr, qcoh, qa = read_model_folder(folder, bits, p + 1)
+            self.set_model(p, bank, qstr, qcoh, qa)
+
+    def set_model(self, pass_index, bank, qstr, qcoh, quant_angle):
+        bank = np.ascontiguousarray(bank, np.float32)
+        qstr = np.ascontiguousarray(qstr, np.float32); qcoh = np.ascontiguousarray(qcoh, np.float32)
+        hk, pt, _ = bank.shape
+        _check(lib().raisr_hip_set_model(self._h, pass_index, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
+                                         quant_angle), "raisr_hip_set_model")
+
+    def set_model_blob_device(self, pass_index, dev_ptr, nbytes, stream=None):
+        _check(lib().raisr_hip_set_model_blob_device(self._h, pass_index, dev_ptr, nbytes, stream), "set_model_blob_device")
+
+    def configure(self, in_w, in_h, out_w, out_h, bits=8, full_range=False, passes=1, mode=1, hash_variant=HASH_AVX512,
+                  blending=BLEND_COUNT, ratio2=None, tie=TIE_HALF_UP):
+        lo, hi = clamp_range(bits, full_range)
+        c = RaisrHipConfig()
+        c.in_width, c.in_height, c.out_width, c.out_height = in_w, in_h, out_w, out_h
+        c.bits, c.clamp_lo, c.clamp_hi = bits, lo, hi
+        c.passes, c.two_pass_mode = passes, mode
+        c.hash_variant, c.blending = hash_variant, blending
+        c.use_pixel_type = int(out_w == 2 * in_w and out_h == 2 * in_h) if ratio2 is None else int(ratio2)
+        c.tie_rule = tie
+        _check(lib().raisr_hip_configure(self._h, ctypes.byref(c)), "raisr_hip_configure")
+        self.cfg = c
+
+    def process_y(self, d_in, in_pitch, d_out, out_pitch, stream=None):
+        _check(lib().raisr_hip_process_y_device(self._h, d_in, in_pitch, d_out, out_pitch, stream), "raisr_hip_process_y_device")
+
+    def resize_plane(self, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream=None):
+        _check(lib().raisr_hip_resize_plane_device(self._h, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream),
+               "raisr_hip_resize_plane_device")
+
+    def process_host(self, y, oy, u=None, ou=None, v=None, ov=None):
+        def pp(a):
+            return (a.ctypes.data, a.strides[0]) if a is not None else (None, 0)
+        args = [*pp(y), *pp(oy), *pp(u), *pp(ou), *pp(v), *pp(ov)]
+        cw, ch = (u.shape[1], u.shape[0]) if u is not None else (0, 0)
+        ocw, och = (ou.shape[1], ou.shape[0]) if ou is not None else (0, 0)
+        _check(lib().raisr_hip_process_host(self._h, *args, cw, ch, ocw, och), "raisr_hip_process_host")
+
+    def synchronize(self):
+        _check(lib().raisr_hip_synchronize(self._h), "raisr_hip_synchronize")
+
+    def read_stage(self, pass_index=0):
+        mode2 = self.cfg.passes == 2 and self.cfg.two_pass_mode == 2
+        w = self.cfg.in_width if (pass_index == 0 and mode2) else self.cfg.out_width
+        h = self.cfg.in_height if (pass_index == 0 and mode2) else self.cfg.out_height
+        hs = np.zeros((h, w), np.uint16); hr = np.zeros((h, w), np.float32)
+        _check(lib().raisr_hip_debug_read_stage(self._h, pass_index, hs.ctypes.data, hr.ctypes.data), "debug_read_stage")
+        return hs, hr
+
+    def timing_enable(self, on=True):
+        _check(lib().raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
+
+    def timing_read(self, max_kernels=16):
+        names = ctypes.create_string_buffer(64 * max_kernels)
+        ms = (ctypes.c_float * max_kernels)(); cnt = (ctypes.c_int * max_kernels)()
+        n = lib().raisr_hip_kernel_timing_read(self._h, names, ms, cnt, max_kernels)
+        if n < 0:
+            raise RuntimeError(last_error())
+        out = {}
+        for i in range(n):
+            nm = names.raw[64 * i:64 * (i + 1)].split(b"\0")[0].decode()
+            out[nm] = {"total_ms": float(ms[i]), "count": int(cnt[i])}
+        return out
