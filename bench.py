@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    ap.add_argument("--frame-kind", default="natural", choices=["natural", "constant", "random", "checker"])
     return ap.parse_args()
 
 
@@ -69,6 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     import raisr_hip as R
+    import sharding
     import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,14 +87,12 @@ def main():
     passes = args.passes
     blobs = []
     for p in range(passes):
+        host_blob = None
         if rank == 0:
             bank, qstr, qcoh, qa = R.read_model_folder(FOLDER, 8, p + 1)
-            blob = torch.from_numpy(R.pack_model_blob(bank, qstr, qcoh, qa)).to(dev)
-        else:
-            blob = torch.empty(R.lib().raisr_hip_model_blob_bytes(216, 4), dtype=torch.uint8, device=dev)
-        if world > 1:
-            dist.broadcast(blob, src=0)
-        blobs.append(blob)
+            host_blob = R.pack_model_blob(bank, qstr, qcoh, qa)
+        nbytes = R.lib().raisr_hip_model_blob_bytes(216, 4)
+        blobs.append(sharding.broadcast_model_blob(host_blob, nbytes, dev, dist if world > 1 else None))
     torch.cuda.synchronize()
 
     lanes = []
@@ -106,7 +106,14 @@ def main():
     # ---- synthetic input, resident in HBM before the timed region ----
     nf = args.frames_per_step
     uniq = min(nf, 8)
-    host_frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + rank * 1000 + i) for i in range(uniq)]
+    # each rank owns its own frames of the (virtual) stream: frame index = rank + world * i
+    mine = sharding.frames_for_rank(uniq * world, rank, world)
+    if args.frame_kind == "natural":
+        host_frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + i) for i in mine]
+    elif args.frame_kind == "random":
+        host_frames = [synth.random_y(IN_W, IN_H, 8, seed=777 + i) for i in mine]
+    else:
+        host_frames = [synth.FRAME_KINDS[args.frame_kind](IN_W, IN_H, 8) for _ in mine]
     d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
     d_out = [torch.empty((OUT_H, OUT_W), dtype=torch.uint8, device=dev) for _ in range(args.lanes)]
     torch.cuda.synchronize()
@@ -134,10 +141,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, dev, dist if world > 1 else None)
 
     # per-kernel event timings (rank 0's lanes)
     kern = {}
@@ -182,6 +186,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"1080p->4K 2x, filters_2x/filters_highres, {passes}-pass, 8-bit, CT blend, "
                                    "AVX512-exact numerics, frames resident in HBM",
+                       "frame_kind": args.frame_kind,
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "parallelism": f"frame-shard x{world}"},
             "kernels_avg_ms": kernels_ms,

@@ -87,6 +87,7 @@ void ora_resize_bilinear(const uint16_t *src, int sw, int sh, int sstride,
     int *x0 = (int *)malloc(sizeof(int) * dw), *x1 = (int *)malloc(sizeof(int) * dw);
     int64_t *fx = (int64_t *)malloc(sizeof(int64_t) * dw);
     for (int x = 0; x < dw; x++) axis_tap(x, sw, dw, &x0[x], &x1[x], &fx[x]);
+    #pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++) {
         int y0, y1; int64_t fy;
         axis_tap(y, sh, dh, &y0, &y1, &fy);
@@ -267,8 +268,8 @@ void ora_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t *o
     size_t n = (size_t)W * H;
     float *L = (float *)malloc(n * sizeof(float));
     float *HR = (float *)malloc(n * sizeof(float));
-    for (size_t i = 0; i < n; i++) L[i] = (float)lr[i];            /* ippiConvert_*32f: exact */
-    memcpy(HR, L, n * sizeof(float));                              /* Raisr.cpp:1035 */
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) { L[i] = (float)lr[i]; HR[i] = L[i]; }   /* ippiConvert_*32f (exact); HR := LR, Raisr.cpp:1035 */
     if (hash_dump) for (size_t i = 0; i < n; i++) hash_dump[i] = -1;
     const float lo = (float)P->lo, hi = (float)P->hi;
     const int randomness = P->blending == ORA_BLEND_RANDOMNESS;

@@ -73,7 +73,7 @@ int main(int argc, char **argv)
     /* every normal exponent x a spread of mantissas */
     uint32_t lcg = 12345u;
     for (uint32_t e = 1; e < 255; e++)
-        for (int k = 0; k < 64; k++) {
+        for (int k = 0; k < 12; k++) {
             lcg = lcg * 1664525u + 1013904223u;
             uint32_t b = (e << 23) | (lcg >> 9);
             fprintf(f, "%08x %08x %08x %08x %08x\n", b, do_rcp14(b), do_rsqrt14(b), do_rcp(b), do_rsqrt(b));

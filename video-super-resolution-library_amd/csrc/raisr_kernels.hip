@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -179,7 +180,7 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
 __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
 template <int R>
-__global__ __launch_bounds__(256, 4) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
+__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
                                                   uint16_t* __restrict__ hash_out)
 {
     constexpr int TH = 4 * R;
@@ -584,10 +585,11 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     PassParams P = make_pass(c, pass, W, H);
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
-        constexpr int R = 4;
+        static const int R = []{ const char* e = getenv("RAISR_HIP_HASH_R"); return (e && atoi(e) == 8) ? 8 : 4; }();
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         timer_begin(c, "k_hash", s, slot);
-        hipLaunchKernelGGL((k_hash<R>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
+        if (R == 8) hipLaunchKernelGGL((k_hash<8>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
+        else hipLaunchKernelGGL((k_hash<4>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
         timer_end(c, s, slot);
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         timer_begin(c, "k_filter", s, slot);

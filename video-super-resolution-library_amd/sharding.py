@@ -1,0 +1,37 @@
+"""Multi-GPU plumbing for the frame-sharded RAISR job (one process per GPU).
+
+Frames are independent (RNLProcess is a pure per-frame function, reference Library/Raisr.cpp:1294),
+so frame i of a stream goes to rank i mod world and no rank ever exchanges pixels.  The only
+collective is one broadcast of the packed filter-bank blob(s) from the rank that read the model
+files: RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.
+"""
+import numpy as np
+
+
+def frames_for_rank(n_frames, rank, world):
+    """Indices of the frames rank `rank` owns under round-robin sharding."""
+    return list(range(rank, n_frames, world))
+
+
+def broadcast_model_blob(blob, nbytes, device, dist=None, src=0):
+    """blob: numpy uint8 array on the source rank (None elsewhere).  Returns a torch uint8 tensor of
+    `nbytes` on `device` holding the same bytes on every rank."""
+    import torch
+    if blob is not None:
+        t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8)).to(device)
+        assert t.numel() == nbytes
+    else:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def max_over_ranks(value, device, dist=None):
+    """MAX-reduce a python float over ranks (bench timing contract)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
