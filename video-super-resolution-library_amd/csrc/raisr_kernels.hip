@@ -114,15 +114,85 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
     dst[(size_t)y * R.dpitch + x] = (TOut)q;
 }
 
+// 2x special case of the same arithmetic: weights {1,3}/4 per axis, out = (sum + 8) >> 4
+// (ties: +8 then >>4 is round-half-up; the half-even switch subtracts one when the discarded
+// bits are exactly 8 and the quotient is odd).  One thread produces 4 adjacent output pixels.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);       // group of 4 output columns
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = 4 * t;
+    if (x0 >= R.dw || y >= R.dh) return;
+    const int sy = y >> 1;
+    const int ya = (y & 1) ? sy : max(sy - 1, 0);             // far/near rows: even y -> (sy-1: 1, sy: 3)
+    const int yb = (y & 1) ? min(sy + 1, R.sh - 1) : sy;      //                odd  y -> (sy: 3, sy+1: 1)
+    const int wa = (y & 1) ? 3 : 1, wb = 4 - wa;
+    const TIn* ra = src + (size_t)ya * R.spitch;
+    const TIn* rb = src + (size_t)yb * R.spitch;
+    const int c = 2 * t;                                      // source columns c-1 .. c+2
+    const int cm = max(c - 1, 0), c1 = min(c + 1, R.sw - 1), c2 = min(c + 2, R.sw - 1), cc = min(c, R.sw - 1);
+    const int a0 = ra[cm], a1 = ra[cc], a2 = ra[c1], a3 = ra[c2];
+    const int b0 = rb[cm], b1 = rb[cc], b2 = rb[c1], b3 = rb[c2];
+    const int v0 = wa * a0 + wb * b0, v1 = wa * a1 + wb * b1, v2 = wa * a2 + wb * b2, v3 = wa * a3 + wb * b3;
+    int o[4] = {v0 + 3 * v1, 3 * v1 + v2, v1 + 3 * v2, 3 * v2 + v3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = (o[i] + 8) >> 4;
+        if (R.tie_even && ((o[i] & 15) == 8) && (q & 1)) q--;
+        o[i] = q;
+    }
+    TOut* d = dst + (size_t)y * R.dpitch + x0;
+    if (x0 + 3 < R.dw) {
+        if (sizeof(TOut) == 2 && ((reinterpret_cast<uintptr_t>(d) & 7) == 0)) {
+            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+        } else if (sizeof(TOut) == 1 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
+            *reinterpret_cast<unsigned*>(d) = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16) | ((unsigned)o[3] << 24);
+        } else {
+            d[0] = (TOut)o[0]; d[1] = (TOut)o[1]; d[2] = (TOut)o[2]; d[3] = (TOut)o[3];
+        }
+    } else {
+        for (int i = 0; i < 4 && x0 + i < R.dw; i++) d[i] = (TOut)o[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
 // (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
 // ------------------------------------------------------------------------------------------------
+// sqrt14(v) = VRCP14(VRSQRT14(v)).  Fast path: v normal, positive and finite (then both table
+// evaluations stay in the normal range: the rsqrt14 result has a biased exponent in [62,190]) and
+// v == +0 (-> rcp14(+inf) = +0); everything else (negative, NaN, inf, denormal) takes the generic
+// models of x86_approx_dev.h.
+__device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab)
+{
+    const uint32_t x = __float_as_uint(v);
+    if (x - 0x00800000u < 0x7f000000u) {
+        const int E = (int)(x >> 23);
+        uint32_t m = x & 0x7fffffu;
+        const int ue = E - 127, p = ue & 1, half = (ue - p) >> 1;
+        uint2 c = tab[64 + 32 * p + (m >> 18)];
+        uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;
+        uint32_t y = ((uint32_t)(126 - half) << 23) | (code << 7);
+        if ((p | m) == 0) y = (uint32_t)(127 - half) << 23;                 // exact power of four
+        // rcp14 of the (normal) intermediate
+        const int Ey = (int)(y >> 23);
+        m = y & 0x7fffffu;
+        c = tab[m >> 17];
+        code = (c.x - c.y * ((m >> 7) & 1023u)) >> 9;
+        uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code << 7);
+        if (m == 0) z = (uint32_t)(254 - Ey) << 23;
+        return __uint_as_float(z);
+    }
+    if (x == 0u) return 0.0f;
+    return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+}
+
 template <bool LEGACY>
 __device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut)
 {
     if (LEGACY) return x86dev::rcp_legacy(x86dev::rsqrt_legacy(v, lut + 2048), lut);
-    return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+    return sqrt14_fast(v, tab);
 }
 
 template <bool LEGACY>
@@ -141,10 +211,12 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
     const float ONEQTR_PI = (float)(3.14159265358979323846 / 4.0);          // (float)(M_PI/4.0)
     const float THRQTR_PI = (float)(3.0 * 3.14159265358979323846 / 4.0);    // (float)(3.0*M_PI/4.0)
     const float ay = __builtin_fabsf(b) + 1e-10f;
-    const float r1 = (xx + ay) / (ay - xx);
-    const float r2 = (xx - ay) / (xx + ay);
+    // r = x<0 ? (x+|y|)/(|y|-x) : (x-|y|)/(x+|y|): select the operands, divide once (same IEEE op)
     const bool neg = xx < 0.0f;
-    const float rr = neg ? r1 : r2;
+    const float xpa = xx + ay;
+    const float num = neg ? xpa : (xx - ay);
+    const float den = neg ? (ay - xx) : xpa;
+    const float rr = num / den;
     float ang = neg ? THRQTR_PI : ONEQTR_PI;
     ang = __builtin_fmaf(__builtin_fmaf(0.1963f * rr, rr, -0.9817f), rr, ang);
     const float nang = -1.0f * ang;
@@ -298,7 +370,7 @@ __device__ __forceinline__ float tree16(float acc)
 __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hash,
                                                 PassParams P, float* __restrict__ hr)
 {
-    constexpr int TW = 64, TH = 16, LW = TW + 10, LH = TH + 10;
+    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
     __shared__ float sL[LH * LW];
     __shared__ uint16_t sH[TH * TW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -307,7 +379,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
 
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
-        for (int tx = lane; tx < LW; tx += 64) {
+        for (int tx = lane; tx < TW + 10; tx += 64) {
             const int gx = min(max(c0 - 5 + tx, 0), P.W - 1);
             sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
         }
@@ -322,7 +394,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
         const int k = 16 * ch + l;
-        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : -1;
+        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
     }
 
 #pragma unroll 1
@@ -341,7 +413,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
             const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
             float p[8];
 #pragma unroll
-            for (int ch = 0; ch < 8; ch++) p[ch] = (off[ch] >= 0) ? sL[base + off[ch]] : 0.0f;
+            for (int ch = 0; ch < 8; ch++) p[ch] = sL[base + off[ch]];
             float res = center;
             if (hA != 0xFFu) {
                 const float* f = P.bank + ((size_t)(hA * P.pixel_types + t) * kTapsPad + l);
@@ -375,36 +447,70 @@ template <typename TOut>
 __global__ __launch_bounds__(256) void k_blend(const uint16_t* __restrict__ lr, const float* __restrict__ hr,
                                                PassParams P, TOut* __restrict__ out, int out_pitch)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.W || y >= P.H) return;
-    const uint16_t lc = lr[(size_t)y * P.lr_pitch + x];
-    if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
-        out[(size_t)y * out_pitch + x] = (TOut)lc;
-        return;
-    }
-    const float Lc = (float)lc;
-    auto inzone = [&](int yy, int xx) { return yy >= kMargin && yy < P.H - kMargin && xx >= kMargin && xx < P.c_final; };
-    const float Hc = inzone(y, x) ? hr[(size_t)y * P.hr_pitch + x] : Lc;
-    int hd = 0;
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-            if (dx == 0 && dy == 0) continue;
-            const float Ln = (float)lr[(size_t)(y + dy) * P.lr_pitch + x + dx];
-            const float Hn = inzone(y + dy, x + dx) ? hr[(size_t)(y + dy) * P.hr_pitch + x + dx] : Ln;
-            const int bl = Ln < Lc, bh = Hn < Hc;
-            hd += (bl != bh);
+    // tile 64 x 16 output pixels; wave w owns rows [4w, 4w+4), lane = column.  LR/HR tiles with a
+    // 1-px halo are staged in LDS (HR := LR outside the filtered zone, Raisr.cpp:1035).
+    constexpr int TW = 64, TH = 16, LW = TW + 2, LH = TH + 2;
+    __shared__ float sL[LH * LW];
+    __shared__ float sH[LH * LW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
+        const bool rowz = gy >= kMargin && gy < P.H - kMargin;
+        for (int tx = lane; tx < LW; tx += 64) {
+            const int gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+            const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
+            float Hv = L;
+            if (rowz && gx >= kMargin && gx < P.c_final) Hv = hr[(size_t)gy * P.hr_pitch + gx];
+            sL[ty * LW + tx] = L;
+            sH[ty * LW + tx] = Hv;
         }
-    const float weight = (float)hd * 0.125f;                   // hd / 8.0f exactly
-    const float w2 = 1.0f - weight;
-    float val = (weight * Lc) + (w2 * Hc);
-    val = val + 0.5f;
-    const float fl = __builtin_floorf(val);
-    int iv = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
-    iv = max(min(iv, P.ihi), P.ilo);
-    out[(size_t)y * out_pitch + x] = (TOut)iv;
+    }
+    __syncthreads();
+    const int x = c0 + lane;
+    if (x >= P.W) return;
+    // sliding 3-row window down the wave's 4 rows
+    float l[3][3], h[3][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            l[i + 1][j] = sL[(4 * w + i) * LW + lane + j];
+            h[i + 1][j] = sH[(4 * w + i) * LW + lane + j];
+        }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int y = r0 + 4 * w + rr;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            l[0][j] = l[1][j]; l[1][j] = l[2][j]; h[0][j] = h[1][j]; h[1][j] = h[2][j];
+            l[2][j] = sL[(4 * w + rr + 2) * LW + lane + j];
+            h[2][j] = sH[(4 * w + rr + 2) * LW + lane + j];
+        }
+        if (y >= P.H) break;
+        const float Lc = l[1][1], Hc = h[1][1];
+        int iv;
+        if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
+            iv = (int)Lc;                                       // unclamped LR copy
+        } else {
+            int hd = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (i == 1 && j == 1) continue;
+                    hd += ((l[i][j] < Lc) != (h[i][j] < Hc));
+                }
+            const float weight = (float)hd * 0.125f;           // hd / 8.0f exactly
+            const float w2 = 1.0f - weight;
+            float val = (weight * Lc) + (w2 * Hc);
+            val = val + 0.5f;
+            const float fl = __builtin_floorf(val);
+            iv = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
+            iv = max(min(iv, P.ihi), P.ilo);
+        }
+        out[(size_t)y * out_pitch + x] = (TOut)iv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,10 +656,15 @@ ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch,
 template <typename TIn, typename TOut>
 void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, const ResizeParams& R, const char* name)
 {
-    dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
     int slot;
     timer_begin(c, name, s, slot);
-    hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
+        dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else {
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    }
     timer_end(c, s, slot);
 }
 
@@ -596,7 +707,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         hipLaunchKernelGGL(k_filter, gf, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, c->d_hr[pass]);
         timer_end(c, s, slot);
     }
-    dim3 gb((W + 63) / 64, (H + 3) / 4);
+    dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend", s, slot);
     hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
