@@ -69,16 +69,17 @@ const char *raisr_hip_last_error(void);        /* thread-local text of the last 
 const char *raisr_hip_version(void);
 
 /* Model -------------------------------------------------------------------------------------
- * bank: [hashkeys][pixel_types][121] fp32 in file order (filterbin payload); thresholds as read
- * from the Qfactor files.  pass_index 0 = first pass, 1 = second pass ("_2" files).
- * The packed device blob (bank padded to 128 taps + thresholds) can be exported/imported so that
+ * bank: [hashkeys][pixel_types][121] fp32 in file order (filterbin payload); thresholds are the
+ * std::stod() values of the Qfactor tokens (double: the library derives both the (float) and the
+ * (_Float16) flavours the reference's fp32 / fp16 loaders use).  pass_index 0 = first pass, 1 = second pass ("_2" files).
+ * The packed device blob (fp32 bank padded to 128 taps + binary16 bank + thresholds) can be exported/imported so that
  * one rank loads the files and the others receive the blob by an RCCL broadcast. */
 int    raisr_hip_set_model(raisr_hip_ctx *ctx, int pass_index, const float *bank,
-                           int hashkeys, int pixel_types, const float qstr[2], const float qcoh[2],
+                           int hashkeys, int pixel_types, const double qstr[2], const double qcoh[2],
                            int quant_angle);
 size_t raisr_hip_model_blob_bytes(int hashkeys, int pixel_types);
 int    raisr_hip_pack_model_blob(void *host_blob, const float *bank, int hashkeys, int pixel_types,
-                                 const float qstr[2], const float qcoh[2], int quant_angle);
+                                 const double qstr[2], const double qcoh[2], int quant_angle);
 int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const void *device_blob,
                                        size_t bytes, void *stream);
 

@@ -134,3 +134,59 @@ def upscale_y(plane, folder, ratio=2.0, bits=8, full_range=False, passes=1, mode
     if passes == 2:
         p2 = make_pass(Model(folder, bits, 2), bits, full_range, asm, blending)
     return process_y(plane, out_w, out_h, p1, p2, passes, mode, tie)
+
+
+# ------------------------------------------------------------------------------------------------
+# AVX512-FP16 path (binary16 arithmetic, 8-bit content)
+# ------------------------------------------------------------------------------------------------
+class OraPass16(ctypes.Structure):
+    _fields_ = [("bits", ctypes.c_int), ("lo", ctypes.c_int), ("hi", ctypes.c_int),
+                ("pixel_types", ctypes.c_int), ("blending", ctypes.c_int),
+                ("qangle", ctypes.c_uint16), ("qstr", ctypes.c_uint16 * 2), ("qcoh", ctypes.c_uint16 * 2),
+                ("bank", ctypes.c_void_p)]
+
+
+def _h(x):
+    """python float (double) -> binary16 bit pattern, single RNE rounding"""
+    return int(np.array([x], dtype=np.float64).astype(np.float16).view(np.uint16)[0])
+
+
+def make_pass16(folder, bits, pass_no, full_range=False, blending=BLEND_COUNT):
+    """Model conversion of ReadTrainedData<_Float16> (Raisr.cpp:344-350,375,411): weights
+    (fp16)(float), thresholds (fp16)stod(token), gQAngle (float) -> fp16."""
+    m = Model(folder, bits, pass_no)
+    lo, hi = clamp_range(bits, full_range)
+    p = OraPass16()
+    p.bits, p.lo, p.hi = bits, lo, hi
+    p.pixel_types, p.blending = m.pixel_types, blending
+    qangle32 = np.float32(np.float32(m.qa) / np.float32(3.141592653))
+    p.qangle = int(np.array([qangle32]).astype(np.float16).view(np.uint16)[0])
+    sfx = f"_2_{bits}" + ("_2" if pass_no == 2 else "")
+    qs = [float(t) for t in open(os.path.join(folder, "Qfactor_strbin" + sfx)).read().split()]
+    qc = [float(t) for t in open(os.path.join(folder, "Qfactor_cohbin" + sfx)).read().split()]
+    p.qstr[0], p.qstr[1] = _h(qs[0]), _h(qs[1])
+    p.qcoh[0], p.qcoh[1] = _h(qc[0]), _h(qc[1])
+    p._bank_keepalive = np.ascontiguousarray(m.bank.astype(np.float16).view(np.uint16))
+    p.bank = p._bank_keepalive.ctypes.data
+    return p
+
+
+def run_pass16(lr, p, dumps=False):
+    lr = _u16(lr)
+    h, w = lr.shape
+    out = np.zeros((h, w), dtype=np.uint16)
+    hd = np.empty((h, w), dtype=np.int32) if dumps else None
+    hr = np.empty((h, w), dtype=np.uint16) if dumps else None
+    lib().ora16_pass(lr.ctypes.data_as(ctypes.c_void_p), w, h, ctypes.byref(p), out.ctypes.data_as(ctypes.c_void_p),
+                     hd.ctypes.data_as(ctypes.c_void_p) if dumps else None,
+                     hr.ctypes.data_as(ctypes.c_void_p) if dumps else None)
+    return (out, hd, hr) if dumps else out
+
+
+def process_y16(plane, out_w, out_h, p1, p2=None, passes=1, mode=1, tie=TIE_HALF_UP):
+    src = _u16(plane)
+    h, w = src.shape
+    out = np.zeros((out_h, out_w), dtype=np.uint16)
+    lib().ora16_process_y(src.ctypes.data_as(ctypes.c_void_p), w, h, out.ctypes.data_as(ctypes.c_void_p), out_w, out_h,
+                          passes, mode, ctypes.byref(p1), ctypes.byref(p2 if p2 is not None else p1), tie)
+    return out

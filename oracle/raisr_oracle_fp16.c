@@ -1,1 +1,361 @@
-/* placeholder until the fp16 restatement lands */ int ora_fp16_available(void) { return 0; }
+/*
+ * raisr_oracle_fp16.c -- TEST INFRASTRUCTURE.  CPU restatement of the reference's AVX512-FP16 path
+ * (ASMType AVX512_FP16), whole-frame semantics, 8-bit content.  Same rules as raisr_oracle.c: only
+ * tests/, smoke() and bench.py's cpu_baseline leg may load it; PARITY UNPINNED for the same reasons
+ * (no reference vectors, reference unbuildable without Intel IPP).  Pinned pieces: VRCPPH/VRSQRTPH
+ * are modelled exactly (x86_fp16_tables.h, all 65536 inputs) and the software binary16 arithmetic
+ * below is checked against results captured from real AVX512-FP16 hardware (tests/golden/
+ * fp16_arith_hw.bin).
+ *
+ * Every binary16 value is carried as its uint16 bit pattern; each h_* helper is ONE IEEE-754
+ * binary16 operation with round-to-nearest-even, subnormals preserved (AVX512-FP16 ignores MXCSR
+ * FTZ/DAZ), matching one intrinsic of the cited lines:
+ *   computeGTWG_Segment_AVX512FP16_16f   Library/Raisr_AVX512FP16.cpp:138-224 (tree :67-75)
+ *   GetHashValue_AVX512FP16_16h_32/8     :497-590 / :382-471, atan2 approximation :358-380,:473-495
+ *   DotProdPatch_AVX512FP16_16f          :227-242 (tree :77-109)
+ *   CTCountOfBitsChangedSegment_AVX512FP16_16f  :258-355
+ *   model conversion to binary16         Library/Raisr.cpp:344-350,375,411
+ *   column driver (unroll 32 -> 8)       Library/Raisr.cpp:1058-1250
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "x86_fp16_tables.h"
+
+#if defined(__FAST_MATH__)
+#error "the oracle must be compiled without -ffast-math"
+#endif
+
+typedef uint16_t h16;
+
+#define PATCH 11
+#define PM 5
+#define LM 6
+#define TAPS 121
+
+/* ---------------- software binary16 ---------------- */
+static inline float h2f(h16 h)
+{
+    uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u, u;
+    if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else if (e == 0) {
+        if (!m) u = s;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; sh++; } u = s | ((uint32_t)(113 - sh) << 23) | ((m & 1023u) << 13); }
+    } else u = s | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+/* round a double to binary16, nearest-even (single rounding from the double) */
+static inline h16 d2h(double d)
+{
+    uint64_t u; memcpy(&u, &d, 8);
+    h16 s = (h16)((u >> 48) & 0x8000u);
+    int e = (int)((u >> 52) & 0x7ff);
+    uint64_t m = u & 0xfffffffffffffull;
+    if (e == 0x7ff) return (h16)(s | 0x7c00u | (m ? (0x200u | (h16)(m >> 42)) : 0));
+    if (e == 0) return s;                                   /* double subnormals are far below half range */
+    int he = e - 1023 + 15;
+    uint64_t sig = m | (1ull << 52);                        /* 53-bit significand */
+    int shift = 42;                                         /* keep 11 bits */
+    if (he >= 31) return (h16)(s | 0x7c00u);
+    if (he <= 0) { shift += 1 - he; he = 0; if (shift > 63) return s; }
+    uint64_t q = sig >> shift, rem = sig & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (q & 1))) q++;
+    /* q may carry into the next exponent; adding handles it: for he>0 q has the implicit bit at 1<<10 */
+    uint32_t r = (he > 0) ? (((uint32_t)(he - 1) << 10) + (uint32_t)q) : (uint32_t)q;
+    if (r >= 0x7c00u) return (h16)(s | 0x7c00u);
+    return (h16)(s | r);
+}
+static inline h16 f2h(float f) { return d2h((double)f); }
+
+static inline h16 h_add(h16 a, h16 b) { return f2h(h2f(a) + h2f(b)); }   /* float sum is exact or innocuously rounded */
+static inline h16 h_sub(h16 a, h16 b) { return f2h(h2f(a) - h2f(b)); }
+static inline h16 h_mul(h16 a, h16 b) { return f2h(h2f(a) * h2f(b)); }   /* 22-bit product: exact in float */
+static inline h16 h_div(h16 a, h16 b) { return f2h(h2f(a) / h2f(b)); }   /* 24 >= 2*11+2: double rounding innocuous */
+static inline h16 h_fma(h16 a, h16 b, h16 c)
+{
+    double p = (double)h2f(a) * (double)h2f(b);              /* exact */
+    double cc = (double)h2f(c);
+    double s = p + cc;
+    if (isfinite(s)) {
+        double t = s - p;
+        double err = (p - (s - t)) + (cc - t);               /* TwoSum: exact rounding error of s */
+        if (err != 0.0) {                                    /* round-to-odd so the final rounding is single */
+            uint64_t u; memcpy(&u, &s, 8);
+            if (!(u & 1)) { s = nextafter(s, err > 0 ? INFINITY : -INFINITY); }
+        }
+    }
+    return d2h(s);
+}
+static inline int h_lt(h16 a, h16 b) { return h2f(a) < h2f(b); }
+static inline int h_le(h16 a, h16 b) { return h2f(a) <= h2f(b); }
+static inline h16 h_abs(h16 a) { return (h16)(a & 0x7fffu); }
+static inline h16 h_from_int(int v) { return d2h((double)v); }
+/* _mm512_cvt_roundph_epi16(x, TO_NEG_INF): NaN / out of range -> 0x8000 */
+static inline int16_t h_floor_i16(h16 a)
+{
+    float f = floorf(h2f(a));
+    if (!(f >= -32768.0f && f <= 32767.0f)) return (int16_t)0x8000;
+    return (int16_t)f;
+}
+
+/* ---------------- VRCPPH / VRSQRTPH ---------------- */
+static inline void h_norm(int *E, uint32_t *m) { int e = 1; uint32_t mm = *m; while (!(mm & 0x400u)) { mm <<= 1; e--; } *E = e; *m = mm & 1023u; }
+
+h16 ora_x86_rcpph(h16 x)
+{
+    uint32_t sign = x & 0x8000u, m = x & 1023u; int E = (x >> 10) & 31;
+    if (E == 31) return (h16)(m ? (x | 0x200u) : sign);
+    if (E == 0) { if (!m) return (h16)(sign | 0x7c00u); h_norm(&E, &m); }
+    uint32_t t = X86_RCPPH_T[m];
+    int re = (int)((t >> 10) & 31u) + (15 - E);
+    if (re >= 31) return (h16)(sign | 0x7c00u);
+    if (re >= 1) return (h16)(sign | ((uint32_t)re << 10) | (t & 1023u));
+    for (int i = 0; i < X86_RCPPH_SUBNORMAL_COUNT; i++)      /* subnormal results: captured list */
+        if (X86_RCPPH_SUBNORMAL_IN[i] == x) return X86_RCPPH_SUBNORMAL_OUT[i];
+    return (h16)sign;
+}
+
+h16 ora_x86_rsqrtph(h16 x)
+{
+    uint32_t sign = x & 0x8000u, m = x & 1023u; int E = (x >> 10) & 31;
+    if (E == 31 && m) return (h16)(x | 0x200u);
+    if (E == 0 && !m) return (h16)(sign | 0x7c00u);
+    if (sign) return 0xfe00u;
+    if (E == 31) return 0;
+    if (E == 0) h_norm(&E, &m);
+    int ue = E - 15, p = ue & 1, half = (ue - p) / 2;
+    uint32_t t = p ? X86_RSQRTPH_T1[m] : X86_RSQRTPH_T0[m];
+    return (h16)((((t >> 10) & 31u) - (uint32_t)half) << 10 | (t & 1023u));
+}
+
+/* ---------------- parameters ---------------- */
+typedef struct {
+    int bits, lo, hi;
+    int pixel_types;
+    int blending;
+    h16 qangle;                 /* (fp16) gQAngle */
+    h16 qstr[2], qcoh[2];       /* (fp16) std::stod(token) */
+    const h16 *bank;            /* [216][pixel_types][121] = (fp16)(float weight) */
+} ora16_pass_t;
+
+/* un-normalised Gaussian literals (gGaussian2DOriginal_fp16_doubled_w1w3, Raisr_globals.h:267-278), (fp16)literal */
+static const double GAUSS_Q16[6][6] = {
+    {7.76554e-05, 0.000239195, 0.0005738, 0.001072, 0.00155975, 0.00176743},
+    {0.000239195, 0.000736774, 0.00176743, 0.00330199, 0.00480437, 0.00544406},
+    {0.0005738, 0.00176743, 0.00423984, 0.00792107, 0.0115251, 0.0130596},
+    {0.001072, 0.00330199, 0.00792107, 0.0147985, 0.0215317, 0.0243986},
+    {0.00155975, 0.00480437, 0.0115251, 0.0215317, 0.0313284, 0.0354998},
+    {0.00176743, 0.00544406, 0.0130596, 0.0243986, 0.0354998, 0.0402265},
+};
+
+void ora16_gaussian_weights(h16 w[PATCH][PATCH])
+{
+    for (int i = 0; i < PATCH; i++)
+        for (int j = 0; j < PATCH; j++)
+            w[i][j] = d2h(GAUSS_Q16[i < 6 ? i : 10 - i][j < 6 ? j : 10 - j]);
+}
+
+static inline h16 tree11_h(const h16 S[PATCH])
+{
+    /* sumitup2lane_AVX512FP16_16f (:67-75): r8[i]=a[i]+a[i+8]; r4[4+j]=r8[4+j]+r8[j];
+     * sum=(r4[4]+r4[6])+(r4[5]+r4[7]).  For all four pixel classes (weights at lanes 1..11, 2..12,
+     * 3..13, 4..14) this is (Gb+Gc)+(Ga+Gd) up to operand order of individual additions, with
+     * Ga=(S0+S8)+S4, Gb=(S1+S9)+S5, Gc=S7+S3, Gd=(S2+S10)+S6. */
+    h16 Ga = h_add(h_add(S[0], S[8]), S[4]);
+    h16 Gb = h_add(h_add(S[1], S[9]), S[5]);
+    h16 Gc = h_add(S[7], S[3]);
+    h16 Gd = h_add(h_add(S[2], S[10]), S[6]);
+    return h_add(h_add(Gb, Gc), h_add(Ga, Gd));
+}
+
+static void gtwg_pixel_h(const h16 *L, int W, int r, int c, const h16 w[PATCH][PATCH], float nf, h16 *a, h16 *b, h16 *d)
+{
+    h16 A[PATCH], B[PATCH], D[PATCH];
+    for (int k = 0; k < PATCH; k++) A[k] = B[k] = D[k] = 0;
+    for (int i = 0; i < PATCH; i++) {
+        int y = r - PM + i;
+        for (int k = 0; k < PATCH; k++) {
+            int x = c - PM + k;
+            h16 gx = h_sub(L[(size_t)(y + 1) * W + x], L[(size_t)(y - 1) * W + x]);
+            h16 gy = h_sub(L[(size_t)y * W + x + 1], L[(size_t)y * W + x - 1]);
+            h16 p = h_mul(gx, w[i][k]);
+            A[k] = h_fma(p, gx, A[k]);
+            B[k] = h_fma(p, gy, B[k]);
+            h16 q = h_mul(gy, w[i][k]);
+            D[k] = h_fma(q, gy, D[k]);
+        }
+    }
+    /* GTWG[..] *= normal : (float)x * normal, converted back to binary16 (:197-221) */
+    *a = f2h(h2f(tree11_h(A)) * nf);
+    *b = f2h(h2f(tree11_h(B)) * nf);
+    *d = f2h(h2f(tree11_h(D)) * nf);
+}
+
+static inline h16 sqrt_ph(h16 v) { return ora_x86_rcpph(ora_x86_rsqrtph(v)); }
+
+static int hash_pixel_h(h16 a, h16 b, h16 d, const ora16_pass_t *P)
+{
+    const h16 c100 = h_from_int(100), one = h_from_int(1), two = h_from_int(2), four = h_from_int(4);
+    const h16 pi = f2h(3.141592653f);
+    const h16 ONEQTR_PI = d2h(M_PI / 4.0), THRQTR_PI = d2h(3.0 * M_PI / 4.0);
+    const h16 k1963 = f2h(0.1963f), kn9817 = f2h(-0.9817f), tiny = f2h(1e-10f), near_zero = d2h(0.00000000000000001);
+    a = h_mul(a, c100); b = h_mul(b, c100); d = h_mul(d, c100);
+    h16 T = h_add(a, d);
+    h16 Dt = h_sub(h_mul(a, d), h_mul(b, b));
+    h16 rad = h_sub(h_div(h_mul(T, T), four), Dt);
+    h16 s = sqrt_ph(rad);
+    h16 hT = h_div(T, two);
+    h16 L1 = h_add(hT, s), L2 = h_sub(hT, s);
+    float bf = h2f(b);
+    h16 xx = (bf < 0.0f || bf > 0.0f) ? h_sub(L1, d) : one;
+    /* atan2 approximation (:358-380) */
+    h16 ay = h_add(h_abs(b), tiny);
+    h16 r1 = h_div(h_add(xx, ay), h_sub(ay, xx));
+    h16 r2 = h_div(h_sub(xx, ay), h_add(xx, ay));
+    int neg = h2f(xx) < 0.0f;
+    h16 rr = neg ? r1 : r2;
+    h16 ang = neg ? THRQTR_PI : ONEQTR_PI;
+    ang = h_fma(h_fma(h_mul(k1963, rr), rr, kn9817), rr, ang);
+    h16 nang = h_mul(h_from_int(-1), ang);
+    ang = (bf < 0.0f) ? nang : ang;
+    ang = h_add(ang, (h2f(ang) < 0.0f) ? pi : (h16)0);
+    h16 sL1 = sqrt_ph(L1), sL2 = sqrt_ph(L2);
+    h16 coh = h_div(h_sub(sL1, sL2), h_add(h_add(sL1, sL2), near_zero));
+    h16 str = h_div(L1, c100);
+    int ai = h_floor_i16(h_mul(ang, P->qangle));
+    if (ai < 0) ai = 0;
+    if (ai > 23) ai = 23;
+    int si = h_le(P->qstr[0], str) + h_le(P->qstr[1], str);
+    int ci = h_le(P->qcoh[0], coh) + h_le(P->qcoh[1], coh);
+    return ai * 9 + si * 3 + ci;
+}
+
+static h16 dot_patch_h(const h16 *L, int W, int r, int c, const h16 *f)
+{
+    h16 acc[32];
+    for (int l = 0; l < 32; l++) {
+        int k = l;
+        acc[l] = h_mul(L[(size_t)(r - PM + k / PATCH) * W + (c - PM + k % PATCH)], f[k]);
+    }
+    for (int ch = 1; ch < 4; ch++)
+        for (int l = 0; l < 32; l++) {
+            int k = 32 * ch + l;
+            h16 pv = 0, fv = 0;
+            if (k < TAPS) { pv = L[(size_t)(r - PM + k / PATCH) * W + (c - PM + k % PATCH)]; fv = f[k]; }
+            acc[l] = h_fma(pv, fv, acc[l]);
+        }
+    h16 r16[16], r8[8];
+    for (int i = 0; i < 16; i++) r16[i] = h_add(acc[i], acc[i + 16]);
+    for (int i = 0; i < 8; i++) r8[i] = h_add(r16[i], r16[i + 8]);
+    h16 s0 = h_add(h_add(r8[0], r8[4]), h_add(r8[2], r8[6]));
+    h16 s1 = h_add(h_add(r8[1], r8[5]), h_add(r8[3], r8[7]));
+    return h_add(s0, s1);
+}
+
+void ora16_pass(const uint16_t *lr, int W, int H, const ora16_pass_t *P, uint16_t *out, int32_t *hash_dump, uint16_t *hr_dump)
+{
+    h16 wg[PATCH][PATCH];
+    ora16_gaussian_weights(wg);
+    float maxv = P->bits == 8 ? 255.0f : (P->bits == 10 ? 1023.0f : 65535.0f);
+    volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
+    size_t n = (size_t)W * H;
+    h16 *L = (h16 *)malloc(n * sizeof(h16)), *HR = (h16 *)malloc(n * sizeof(h16));
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) { L[i] = h_from_int(lr[i]); HR[i] = L[i]; }
+    if (hash_dump) for (size_t i = 0; i < n; i++) hash_dump[i] = -1;
+    const h16 hlo = h_from_int(P->lo), hhi = h_from_int(P->hi);
+
+    /* column driver with unrollSizePatchBased = 32 (Raisr.cpp:1497): only the end column matters,
+     * the 8-wide tail recomputes identical values */
+    int c_end = LM;
+    { int loopItr = 32, c = LM; while (c + loopItr <= W - LM) { if (loopItr > 8 && c + 64 > W - LM) loopItr = 8; c += loopItr; } c_end = c; }
+
+    #pragma omp parallel for schedule(dynamic, 2)
+    for (int r = LM; r < H - LM; r++)
+        for (int c = LM; c < c_end; c++) {
+            h16 a, b, d;
+            gtwg_pixel_h(L, W, r, c, wg, nf, &a, &b, &d);
+            int h = hash_pixel_h(a, b, d, P);
+            int t = (P->pixel_types == 4) ? ((r - PM) % 2) * 2 + ((c - PM) % 2) : 0;
+            h16 v = dot_patch_h(L, W, r, c, P->bank + ((size_t)h * P->pixel_types + t) * TAPS);
+            size_t idx = (size_t)r * W + c;
+            if (hash_dump) hash_dump[idx] = h;
+            if (h_lt(hlo, v) && h_lt(v, hhi)) HR[idx] = v;          /* Raisr.cpp:1188-1192 */
+        }
+
+    for (int c = 0; c < W; c++) { out[c] = lr[c]; out[(size_t)(H - 1) * W + c] = lr[(size_t)(H - 1) * W + c]; }
+    for (int r = 0; r < H; r++) { out[(size_t)r * W] = lr[(size_t)r * W]; out[(size_t)r * W + W - 1] = lr[(size_t)r * W + W - 1]; }
+    const int c_limit = W - 1, c_avx = c_limit - (c_limit % 32) + 1;
+    const h16 eight = h_from_int(8), one = h_from_int(1), halfh = d2h(0.5);
+    #pragma omp parallel for schedule(static)
+    for (int r = 1; r < H - 1; r++)
+        for (int c = 1; c < W - 1; c++) {
+            size_t idx = (size_t)r * W + c;
+            int hd = 0;
+            for (int i = -1; i <= 1; i++)
+                for (int j = -1; j <= 1; j++) {
+                    if (!i && !j) continue;
+                    size_t nn = (size_t)(r + i) * W + c + j;
+                    hd += abs(h_lt(L[nn], L[idx]) - h_lt(HR[nn], HR[idx]));
+                }
+            int iv;
+            if (c < c_avx) {                                          /* vector body: binary16 (:303-312) */
+                h16 weight = h_div(h_from_int(hd), eight);
+                h16 w2 = h_sub(one, weight);
+                h16 val = h_add(h_mul(weight, L[idx]), h_mul(w2, HR[idx]));
+                val = h_add(val, halfh);
+                int16_t fl = h_floor_i16(val);
+                uint16_t u = (fl < 0) ? 0xFFFFu : (uint16_t)fl;      /* cvtepi16_ph then cvtph_epu16 */
+                iv = u;
+                if (iv > P->hi) iv = P->hi;
+                if (iv < P->lo) iv = P->lo;
+            } else {                                                  /* scalar tail: float (:326-352) */
+                float weight = (float)hd / 8.0f;
+                float val = weight * h2f(L[idx]) + (1.0f - weight) * h2f(HR[idx]);
+                val = (float)((double)val + 0.5);
+                float cl = val < (float)P->lo ? (float)P->lo : (val > (float)P->hi ? (float)P->hi : val);
+                iv = (int)cl;
+            }
+            out[idx] = (uint16_t)iv;
+        }
+    if (hr_dump) memcpy(hr_dump, HR, n * sizeof(h16));
+    free(L); free(HR);
+}
+
+void ora_resize_bilinear(const uint16_t *src, int sw, int sh, int sstride, uint16_t *dst, int dw, int dh, int dstride, int tie);
+
+void ora16_process_y(const uint16_t *in, int inW, int inH, uint16_t *out, int outW, int outH,
+                     int passes, int mode, const ora16_pass_t *P1, const ora16_pass_t *P2, int tie)
+{
+    if (passes == 1) {
+        uint16_t *lr = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)outW * outH);
+        ora_resize_bilinear(in, inW, inH, inW, lr, outW, outH, outW, tie);
+        ora16_pass(lr, outW, outH, P1, out, NULL, NULL);
+        free(lr);
+    } else if (mode == 2) {
+        uint16_t *mid = (uint16_t *)calloc((size_t)inW * inH, sizeof(uint16_t));
+        ora16_pass(in, inW, inH, P1, mid, NULL, NULL);
+        uint16_t *lr = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)outW * outH);
+        ora_resize_bilinear(mid, inW, inH, inW, lr, outW, outH, outW, tie);
+        ora16_pass(lr, outW, outH, P2, out, NULL, NULL);
+        free(mid); free(lr);
+    } else {
+        uint16_t *lr = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)outW * outH);
+        uint16_t *mid = (uint16_t *)calloc((size_t)outW * outH, sizeof(uint16_t));
+        ora_resize_bilinear(in, inW, inH, inW, lr, outW, outH, outW, tie);
+        ora16_pass(lr, outW, outH, P1, mid, NULL, NULL);
+        ora16_pass(mid, outW, outH, P2, out, NULL, NULL);
+        free(lr); free(mid);
+    }
+}
+
+/* exported scalar probes for the tests */
+uint16_t ora16_add(uint16_t a, uint16_t b) { return h_add(a, b); }
+uint16_t ora16_mul(uint16_t a, uint16_t b) { return h_mul(a, b); }
+uint16_t ora16_div(uint16_t a, uint16_t b) { return h_div(a, b); }
+uint16_t ora16_fma(uint16_t a, uint16_t b, uint16_t c) { return h_fma(a, b, c); }
+uint16_t ora16_from_double(double d) { return d2h(d); }
+int ora16_hash(uint16_t a, uint16_t b, uint16_t d, const ora16_pass_t *P) { return hash_pixel_h(a, b, d, P); }
+int ora_fp16_available(void) { return 1; }

@@ -23,4 +23,23 @@ CASES = [
     ("2x_highres_8b_full", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, True),
     ("1.5x_highres_8b_1p", "filters_1.5x/filters_highres", (3, 2), 8, 1, 1, 2, False),
     ("1.5x_denoise_8b_2p_m2", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 2, False),
+    # asm 5 = AVX512-FP16 pipeline (binary16 arithmetic); BASELINE config 4 is the last one
+    ("2x_highres_8b_1p_fp16", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 5, False),
+    ("2x_highres_8b_2p_m1_fp16", "filters_2x/filters_highres", (2, 1), 8, 2, 1, 5, False),
+    ("1.5x_denoise_8b_2p_m2_fp16", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 5, False),
 ]
+
+
+def oracle_y(y, case, tie=0):
+    """CPU oracle output for one CASE (fp32 paths -> raisr_oracle.c, asm 5 -> raisr_oracle_fp16.c)."""
+    import oracle_py as O
+    _, fold, (rn, rd), bits, passes, mode, asm, full = case
+    h, w = y.shape
+    ow, oh = w * rn // rd, h * rn // rd
+    if asm == 5:
+        p1 = O.make_pass16(folder(fold), bits, 1, full)
+        p2 = O.make_pass16(folder(fold), bits, 2, full) if passes == 2 else None
+        return O.process_y16(y, ow, oh, p1, p2, passes, mode, tie).astype(dtype_for(bits))
+    p1 = O.make_pass(O.Model(folder(fold), bits, 1), bits, full, asm)
+    p2 = O.make_pass(O.Model(folder(fold), bits, 2), bits, full, asm) if passes == 2 else None
+    return O.process_y(y, ow, oh, p1, p2, passes, mode, tie).astype(dtype_for(bits))

@@ -18,13 +18,8 @@ def _frames(w, h, bits):
 
 
 def _oracle(y, case):
-    import oracle_py as O
-    _, fold, (rn, rd), bits, passes, mode, asm, full = case
-    h, w = y.shape
-    ow, oh = w * rn // rd, h * rn // rd
-    p1 = O.make_pass(O.Model(folder(fold), bits, 1), bits, full, asm)
-    p2 = O.make_pass(O.Model(folder(fold), bits, 2), bits, full, asm) if passes == 2 else None
-    return O.process_y(y, ow, oh, p1, p2, passes, mode).astype(dtype_for(bits))
+    from common import oracle_y
+    return oracle_y(y, case)
 
 
 def _gpu(y, case):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from common import ROOT, folder, CASES, dtype_for
+from common import ROOT, folder, CASES, dtype_for, oracle_y
 
 
 def _p(fold="filters_2x/filters_highres", bits=8, asm=2, full=False, pass_no=1):
@@ -100,8 +100,6 @@ def test_regression_fixtures():
         y = synth.natural_y(96, 64, bits, seed=4242) if bits == 8 else synth.natural_y(96, 64, bits, seed=4242)
         r = synth.random_y(96, 64, bits, seed=99)
         for nm, fr in (("natural", y), ("random", r)):
-            p1 = O.make_pass(O.Model(folder(fold), bits, 1), bits, full, asm)
-            p2 = O.make_pass(O.Model(folder(fold), bits, 2), bits, full, asm) if passes == 2 else None
-            out = O.process_y(fr, 96 * rn // rd, 64 * rn // rd, p1, p2, passes, mode).astype(dtype_for(bits))
+            out = oracle_y(fr, (cid, fold, (rn, rd), bits, passes, mode, asm, full))
             got[f"{cid}/{nm}"] = hashlib.sha256(out.tobytes()).hexdigest()
     assert got == want

@@ -30,7 +30,7 @@ namespace {
 struct PassModel {
     std::vector<float> bank;      // [hashkeys][pixelTypes][121]
     unsigned hashkeys = 0, pixelTypes = 0, rows = 0;
-    std::vector<float> qstr, qcoh;
+    std::vector<double> qstr, qcoh;   // std::stod values; the device layer derives (float) and (_Float16)
 };
 
 struct State {
@@ -75,7 +75,7 @@ bool tokenLooksNumeric(const std::string &tok)
     return true;
 }
 
-RNLERRORTYPE readThresholds(const std::string &path, const char *kind, unsigned expected, std::vector<float> &out)
+RNLERRORTYPE readThresholds(const std::string &path, const char *kind, unsigned expected, std::vector<double> &out)
 {
     std::ifstream f(path);
     if (!f.is_open()) {
@@ -90,7 +90,7 @@ RNLERRORTYPE readThresholds(const std::string &path, const char *kind, unsigned 
                 std::cout << "[RAISR ERROR] " << kind << " corrupted: " << path << std::endl;
                 return RNLErrorBadParameter;
             }
-            out.push_back((float)std::stod(tok));
+            out.push_back(std::stod(tok));
         }
     } catch (const std::exception &) {
         std::cout << "[RAISR ERROR] " << kind << " corrupted: " << path << std::endl;
@@ -227,9 +227,14 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
         std::cout << "ASM Type: OpenCL requested, but OpenCL is not enabled.\n";
         return RNLErrorBadParameter;
     case AVX512_FP16:
-        std::cout << "ASM Type: AVX512FP16 numerics requested, but this build does not provide them.  Changing to AVX512\n";
-        G.hashVariant = RAISR_HIP_HASH_AVX512;
-        std::cout << "ASM Type: HIP gfx950 (AVX512-exact numerics)\n";
+        if (bitDepth == 8) {
+            G.hashVariant = RAISR_HIP_HASH_FP16;
+            std::cout << "ASM Type: HIP gfx950 (AVX512FP16-exact numerics)\n";
+        } else {    // the binary16 pipeline overflows above 8-bit content (1023^2 > 65504)
+            std::cout << "ASM Type: AVX512FP16 numerics requested, but they are defined for 8-bit content only.  Changing to AVX512\n";
+            G.hashVariant = RAISR_HIP_HASH_AVX512;
+            std::cout << "ASM Type: HIP gfx950 (AVX512-exact numerics)\n";
+        }
         break;
     default:   // AVX512, HIP and out-of-range values (the reference also falls back to its best path)
         G.hashVariant = RAISR_HIP_HASH_AVX512;

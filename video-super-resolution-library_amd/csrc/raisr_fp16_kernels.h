@@ -1,0 +1,373 @@
+// raisr_fp16_kernels.h -- gfx950 kernels reproducing the reference's AVX512-FP16 pipeline
+// (ASMType AVX512_FP16; Library/Raisr_AVX512FP16.cpp) in IEEE binary16 arithmetic.
+// Included by raisr_kernels.hip inside its anonymous namespace (after PassParams).
+//
+// Every arithmetic statement below is ONE binary16 operation with round-to-nearest-even and
+// subnormals preserved (v_*_f16 / v_pk_*_f16 under the default gfx9 float mode), in the order of the
+// cited reference lines.  Two things are NOT left to the compiler:
+//   * division: hipcc's native f16 division (v_rcp_f32 + v_div_fixup_f16) is not correctly rounded,
+//     so h_div() forces an IEEE fp32 division of the widened operands and rounds once to binary16
+//     (innocuous double rounding: 24 >= 2*11+2) -- what VDIVPH produces.
+//   * VRCPPH/VRSQRTPH: exponent-separable 1024-entry tables captured from Intel hardware
+//     (x86_fp16_tables.h), staged in LDS.
+#pragma once
+
+typedef _Float16 hf;
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+
+struct GaussW16 {
+    uint32_t wT[11][12];         // wT[k][i] = (w,w) as packed binary16: un-normalised Gaussian, Raisr_globals.h:267-278
+};
+
+struct Pass16 {
+    const uint32_t* bank16;      // [hash][type][4 chunks][16 lanes] half2 = (f[32c+l], f[32c+l+16]), taps >= 121 are +0
+    const uint16_t* tab16;       // rcpph T[1024], rsqrtph T0[1024], T1[1024]
+    uint16_t qangle, qs0, qs1, qc0, qc1;   // binary16 bit patterns
+    float nf;                    // NF_8 (fp32), Raisr_globals.h:208
+    int c_avx;                   // first column of the blend stage's scalar (fp32) tail
+};
+
+__device__ __forceinline__ hf h_bits(uint16_t u) { return __builtin_bit_cast(hf, u); }
+__device__ __forceinline__ uint16_t h_u(hf h) { return __builtin_bit_cast(uint16_t, h); }
+
+__device__ __forceinline__ hf h_div(hf a, hf b)
+{
+    float fa = (float)a, fb = (float)b;
+    asm volatile("" : "+v"(fa), "+v"(fb));      // keep hipcc from folding this back into its fast f16 division
+    float q = fa / fb;
+    asm volatile("" : "+v"(q));
+    return (hf)q;
+}
+
+// (float)x * normal, stored back to binary16 (Raisr_AVX512FP16.cpp:197-221)
+__device__ __forceinline__ hf h_scale_f32(hf x, float nf)
+{
+    float f = (float)x;
+    asm volatile("" : "+v"(f));
+    float p = f * nf;
+    asm volatile("" : "+v"(p));
+    return (hf)p;
+}
+
+// VRSQRTPH / VRCPPH models (tables in LDS: T at [0,1024), T0 at [1024,2048), T1 at [2048,3072))
+__device__ __forceinline__ uint16_t rsqrtph_dev(uint16_t x, const uint16_t* tab)
+{
+    const uint32_t sign = x & 0x8000u;
+    uint32_t m = x & 1023u;
+    int E = (x >> 10) & 31;
+    if (E == 31 && m) return (uint16_t)(x | 0x200u);
+    if (E == 0 && m == 0) return (uint16_t)(sign | 0x7c00u);
+    if (sign) return 0xfe00u;
+    if (E == 31) return 0;
+    if (E == 0) { const int lz = __clz((int)m) - 21; m = (m << lz) & 1023u; E = 1 - lz; }
+    const int ue = E - 15, p = ue & 1, half = (ue - p) >> 1;
+    const uint32_t t = tab[1024 + 1024 * p + m];
+    return (uint16_t)(((((t >> 10) & 31u) - (uint32_t)half) << 10) | (t & 1023u));
+}
+
+// valid for every input whose reciprocal is not subnormal (always true for a VRSQRTPH result)
+__device__ __forceinline__ uint16_t rcpph_dev(uint16_t x, const uint16_t* tab)
+{
+    const uint32_t sign = x & 0x8000u;
+    uint32_t m = x & 1023u;
+    int E = (x >> 10) & 31;
+    if (E == 31) return (uint16_t)(m ? (x | 0x200u) : sign);
+    if (E == 0) {
+        if (m == 0) return (uint16_t)(sign | 0x7c00u);
+        const int lz = __clz((int)m) - 21; m = (m << lz) & 1023u; E = 1 - lz;
+    }
+    const uint32_t t = tab[m];
+    const int re = (int)((t >> 10) & 31u) + (15 - E);
+    if (re >= 31) return (uint16_t)(sign | 0x7c00u);
+    return (uint16_t)(sign | ((uint32_t)max(re, 0) << 10) | (t & 1023u));
+}
+
+__device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab)
+{
+    return h_bits(rcpph_dev(rsqrtph_dev(h_u(v), tab), tab));
+}
+
+// GetHashValue_AVX512FP16_16h_{8,32}Elements (Raisr_AVX512FP16.cpp:382-471,497-590)
+__device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, const uint16_t* tab)
+{
+    const hf c100 = (hf)100.0f, one = (hf)1.0f, two = (hf)2.0f, four = (hf)4.0f;
+    const hf pi = (hf)3.141592653f;
+    const hf ONEQTR_PI = (hf)(3.14159265358979323846 / 4.0);
+    const hf THRQTR_PI = (hf)(3.0 * 3.14159265358979323846 / 4.0);
+    const hf k1963 = (hf)0.1963f, kn9817 = (hf)-0.9817f, tiny = (hf)1e-10f, near_zero = (hf)0.00000000000000001;
+    a = a * c100; b = b * c100; d = d * c100;
+    const hf T = a + d;
+    const hf Dt = (a * d) - (b * b);
+    const hf rad = h_div(T * T, four) - Dt;
+    const hf s = sqrt_ph(rad, tab);
+    const hf hT = h_div(T, two);
+    const hf L1 = hT + s, L2 = hT - s;
+    const hf xx = (b < (hf)0.0f || b > (hf)0.0f) ? (L1 - d) : one;
+    const hf ay = __builtin_fabsf16(b) + tiny;
+    const bool neg = xx < (hf)0.0f;
+    const hf xpa = xx + ay;
+    const hf num = neg ? xpa : (xx - ay);
+    const hf den = neg ? (ay - xx) : xpa;
+    const hf rr = h_div(num, den);
+    hf ang = neg ? THRQTR_PI : ONEQTR_PI;
+    ang = __builtin_fmaf16(__builtin_fmaf16(k1963 * rr, rr, kn9817), rr, ang);
+    const hf nang = (hf)-1.0f * ang;
+    ang = (b < (hf)0.0f) ? nang : ang;
+    ang = ang + ((ang < (hf)0.0f) ? pi : (hf)0.0f);
+    const hf sL1 = sqrt_ph(L1, tab), sL2 = sqrt_ph(L2, tab);
+    const hf coh = h_div(sL1 - sL2, (sL1 + sL2) + near_zero);
+    const hf str = h_div(L1, c100);
+    const float fl = __builtin_floorf((float)(ang * h_bits(Q.qangle)));
+    int ai = (fl >= -32768.0f && fl <= 32767.0f) ? (int)fl : -32768;     // cvt_roundph_epi16, TO_NEG_INF
+    ai = min(23, max(ai, 0));
+    const int si = (int)(h_bits(Q.qs0) <= str) + (int)(h_bits(Q.qs1) <= str);
+    const int ci = (int)(h_bits(Q.qc0) <= coh) + (int)(h_bits(Q.qc1) <= coh);
+    return ai * 9 + si * 3 + ci;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash16: computeGTWG_Segment_AVX512FP16_16f (:138-224) + hash.  Same work shape as k_hash.
+// Column accumulators per patch column, sequential over the 11 patch rows in binary16:
+//   p = gx*w; A = fma(p,gx,A); B = fma(p,gy,B); q = gy*w; D = fma(q,gy,D)
+// folded as (Gb+Gc)+(Ga+Gd) -- the association of sumitup2lane_AVX512FP16_16f (:67-75), which is
+// the same for all four pixel classes up to operand order of single additions -- then scaled by NF
+// in fp32 and rounded back (:197-221).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256, 4) void k_hash16(const uint16_t* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
+                                                    uint16_t* __restrict__ hash_out)
+{
+    constexpr int TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;
+    constexpr int GW_ = 74, GH = TH + 10;
+    __shared__ hf sL[LH * LW];
+    __shared__ hf2 sG[GH * GW_];
+    __shared__ uint16_t sTab[3072];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = kMargin + blockIdx.x * 64, r0 = kMargin + blockIdx.y * TH;
+    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1);
+        for (int tx = lane; tx < LW; tx += 64) {
+            const int gx = min(max(c0 - 6 + tx, 0), P.W - 1);
+            sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];     // exact for 8-bit content
+        }
+    }
+    __syncthreads();
+    for (int ty = w; ty < GH; ty += 4)
+        for (int tx = lane; tx < GW_; tx += 64) {
+            const hf gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+            const hf gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+            sG[ty * GW_ + tx] = (hf2){gxv, gyv};
+        }
+    __syncthreads();
+
+    hf2 curAD[R], holdAD[R], t1AD[R];
+    hf curB[R], holdB[R], t1B[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        curAD[j] = holdAD[j] = t1AD[j] = (hf2){(hf)0.f, (hf)0.f};
+        curB[j] = holdB[j] = t1B[j] = (hf)0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < 11; kk++) {
+        const int k = c_col_order[kk];
+        hf2 g[R + 10];
+#pragma unroll
+        for (int t = 0; t < R + 10; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
+        hf2 AD[R];
+        hf B[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) { AD[j] = (hf2){(hf)0.f, (hf)0.f}; B[j] = (hf)0.f; }
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const hf2 w2 = __builtin_bit_cast(hf2, gw.wT[k][i]);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const hf2 gg = g[i + j];
+                const hf2 pq = gg * w2;
+                AD[j] = __builtin_elementwise_fma(pq, gg, AD[j]);
+                B[j] = __builtin_fmaf16(pq.x, gg.y, B[j]);
+            }
+        }
+        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
+        if (start) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = AD[j]; curB[j] = B[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = curAD[j] + AD[j]; curB[j] = curB[j] + B[j]; }
+        }
+        if (kk == 2 || kk == 8) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { holdAD[j] = curAD[j]; holdB[j] = curB[j]; }
+        }
+        if (kk == 5) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { t1AD[j] = holdAD[j] + curAD[j]; t1B[j] = holdB[j] + curB[j]; }
+        }
+    }
+
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        const hf2 ad = (holdAD[j] + curAD[j]) + t1AD[j];
+        const hf bb = (holdB[j] + curB[j]) + t1B[j];
+        if (r < P.H - kMargin && c < P.c_final) {
+            const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
+            const unsigned hA = (unsigned)hash_px16(a, b, d, Q, sTab);
+            hash_out[(size_t)r * P.hash_pitch + c] = (uint16_t)(hA | 0xFF00u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_filter16: DotProdPatch_AVX512FP16_16f (:227-242): 32 lanes x 4 chunks, then the tree of
+// sumitup_AVX512FP16_16f (:77-109).  16 GPU lanes per pixel; lane l carries the reference's zmm
+// lanes l and l+16 as a packed half2, so a chunk is one 4-byte filter load (the 16 lanes of a
+// pixel read 64 contiguous bytes), two LDS reads and one v_pk_fma_f16:
+//   r16[l] = a[l]+a[l+16] (inside the lane); r8[i]=r16[i]+r16[i+8]; t[i]=r8[i]+r8[i+4];
+//   s0=t0+t2, s1=t1+t3; v=s0+s1      (DPP row rotations by 8, 4, 2, 1)
+// HR plane is binary16 (u16 storage).
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ hf row_ror_h(hf v)
+{
+    const int bits = (int)h_u(v);
+    return h_bits((uint16_t)__builtin_amdgcn_update_dpp(0, bits, CTRL, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(256) void k_filter16(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hash,
+                                                  PassParams P, Pass16 Q, uint16_t* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;
+    __shared__ hf sL[LH * LW];
+    __shared__ uint16_t sH[TH * TW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, l = lane & 15;
+    const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
+
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
+        for (int tx = lane; tx < TW + 10; tx += 64) {
+            const int gx = min(max(c0 - 5 + tx, 0), P.W - 1);
+            sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];
+        }
+    }
+    for (int ty = w; ty < TH; ty += 4) {
+        const int r = r0 + ty, c = c0 + lane;
+        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint16_t)0xFFFFu;
+    }
+    __syncthreads();
+
+    int off0[4], off1[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        const int k0 = 32 * ch + l, k1 = k0 + 16;
+        off0[ch] = (k0 < kTaps) ? (k0 / 11) * LW + (k0 % 11) : 0;     // padding taps: coefficient is +0
+        off1[ch] = (k1 < kTaps) ? (k1 / 11) * LW + (k1 % 11) : 0;
+    }
+    const hf lo = (hf)P.lo, hi = (hf)P.hi;
+
+#pragma unroll 1
+    for (int row = 0; row < 4; row++) {
+        const int prow = 4 * w + row;
+        const int r = r0 + prow;
+        hf keep = (hf)0.0f;
+#pragma unroll 4
+        for (int s = 0; s < 16; s++) {
+            const int pcol = 4 * s + g;
+            const int c = c0 + pcol;
+            const unsigned hA = sH[prow * TW + pcol] & 0xFFu;
+            const int base = prow * LW + pcol;
+            const hf center = sL[base + 5 * LW + 5];
+            const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
+            hf res = center;
+            if (hA != 0xFFu) {
+                const uint32_t* f = Q.bank16 + ((size_t)(hA * P.pixel_types + t) * 64 + l);
+                hf2 acc = (hf2){sL[base + off0[0]], sL[base + off1[0]]} * __builtin_bit_cast(hf2, f[0]);
+#pragma unroll
+                for (int ch = 1; ch < 4; ch++)
+                    acc = __builtin_elementwise_fma((hf2){sL[base + off0[ch]], sL[base + off1[ch]]}, __builtin_bit_cast(hf2, f[16 * ch]), acc);
+                hf v = acc.x + acc.y;                       // a[l] + a[l+16]
+                v = v + row_ror_h<0x128>(v);                // r16[i] + r16[i+8]
+                v = v + row_ror_h<0x124>(v);                // r8[i] + r8[i+4]
+                v = v + row_ror_h<0x122>(v);                // t[i] + t[i+2]
+                v = v + row_ror_h<0x121>(v);                // s0 + s1
+                if (v > lo && v < hi) res = v;
+            }
+            if (s == l) keep = res;
+        }
+        const int c = c0 + 4 * l + g;
+        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = h_u(keep);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blend16: CTCountOfBitsChangedSegment_AVX512FP16_16f (:258-355).  Columns below c_avx use the
+// 32-wide binary16 body (:303-312), the rest the scalar fp32 tail (:326-352).
+// ------------------------------------------------------------------------------------------------
+template <typename TOut>
+__global__ __launch_bounds__(256) void k_blend16(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hr,
+                                                 PassParams P, Pass16 Q, TOut* __restrict__ out, int out_pitch)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 2, LH = TH + 2;
+    __shared__ float sL[LH * LW];
+    __shared__ float sHh[LH * LW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+    for (int ty = w; ty < LH; ty += 4) {
+        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
+        const bool rowz = gy >= kMargin && gy < P.H - kMargin;
+        for (int tx = lane; tx < LW; tx += 64) {
+            const int gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+            const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
+            float Hv = L;
+            if (rowz && gx >= kMargin && gx < P.c_final) Hv = (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]);
+            sL[ty * LW + tx] = L;                 // binary16 values widened exactly
+            sHh[ty * LW + tx] = Hv;
+        }
+    }
+    __syncthreads();
+    const int x = c0 + lane;
+    if (x >= P.W) return;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; rr++) {
+        const int y = r0 + 4 * w + rr;
+        if (y >= P.H) break;
+        const int ty = 4 * w + rr + 1, tx = lane + 1;
+        const float Lc = sL[ty * LW + tx], Hc = sHh[ty * LW + tx];
+        int iv;
+        if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
+            iv = (int)Lc;
+        } else {
+            int hd = 0;
+#pragma unroll
+            for (int i = -1; i <= 1; i++)
+#pragma unroll
+                for (int j = -1; j <= 1; j++) {
+                    if (i == 0 && j == 0) continue;
+                    hd += ((sL[(ty + i) * LW + tx + j] < Lc) != (sHh[(ty + i) * LW + tx + j] < Hc));
+                }
+            if (x < Q.c_avx) {
+                const hf weight = (hf)((float)hd * 0.125f);          // hd / 8 exactly
+                const hf w2 = (hf)1.0f - weight;
+                hf val = (weight * (hf)Lc) + (w2 * (hf)Hc);
+                val = val + (hf)0.5f;
+                const float fl = __builtin_floorf((float)val);
+                int fi = (fl >= -32768.0f && fl <= 32767.0f) ? (int)fl : -32768;
+                if (fi < 0) fi = 0xFFFF;                              // cvtph_epu16 of a negative value
+                iv = max(min(fi, P.ihi), P.ilo);
+            } else {
+                const float weight = (float)hd * 0.125f;
+                float val = (weight * Lc) + ((1.0f - weight) * Hc);
+                val = val + 0.5f;
+                const float cl = val < P.lo ? P.lo : (val > P.hi ? P.hi : val);
+                iv = (int)cl;
+            }
+        }
+        out[(size_t)y * out_pitch + x] = (TOut)iv;
+    }
+}

@@ -38,6 +38,7 @@
 #include "../../include/raisr_hip.h"
 #include "x86_approx_tables.h"
 #include "x86_approx_dev.h"
+#include "x86_fp16_tables.h"
 
 #if defined(__FAST_MATH__)
 #error "raisr_kernels.hip must be compiled without fast-math"
@@ -345,6 +346,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_hash(const uint16_t* 
     }
 }
 
+#include "raisr_fp16_kernels.h"
+
 // ------------------------------------------------------------------------------------------------
 // k_filter: HR = (lo < v < hi) ? v : LR with v = DotProdPatch(patch, bank[hash][type])
 // (Raisr_AVX512.cpp:134-149; accept test Raisr.cpp:1196-1200).  16 lanes per pixel: lane l owns the
@@ -535,10 +538,16 @@ struct BlobHeader {
     uint32_t magic;
     int32_t hashkeys, pixel_types, quant_angle;
     float qangle, qstr[2], qcoh[2];
-    uint32_t pad[7];
+    uint16_t qangle16, qstr16[2], qcoh16[2];   // binary16 flavours for the AVX512-FP16 pipeline
+    uint16_t pad16;
+    uint32_t pad[4];
 };
 static_assert(sizeof(BlobHeader) == kBlobHeader, "blob header size");
 constexpr uint32_t kBlobMagic = 0x52534152u;   // "RASR"
+
+// blob = header | fp32 bank [rows][128] | fp16 bank [rows][4][16] half2
+inline size_t blob_f32_bytes(int rows) { return (size_t)rows * kTapsPad * sizeof(float); }
+inline size_t blob_f16_bytes(int rows) { return (size_t)rows * 64 * sizeof(uint32_t); }
 
 struct ModelDev {
     void* blob = nullptr;
@@ -584,12 +593,12 @@ GaussW make_gauss(int bits)
 // Column plan of the reference's chunk driver (Raisr.cpp:1065-1066,1246-1250).
 void column_plan(int W, int hash_variant, PassParams& P)
 {
-    const int unroll = hash_variant == RAISR_HIP_HASH_AVX512 ? 16 : 8;
+    const int unroll = hash_variant == RAISR_HIP_HASH_AVX512 ? 16 : (hash_variant == RAISR_HIP_HASH_FP16 ? 32 : 8);
     int loopItr = unroll, c = kMargin;
     P.a_begin = P.a_end = P.b_begin = P.b_end = kMargin;
     bool a_any = false, b_any = false;
     while (c + loopItr <= W - kMargin) {
-        if (loopItr == 16) { if (!a_any) { P.a_begin = c; a_any = true; } P.a_end = c + 16; }
+        if (loopItr >= 16) { if (!a_any) { P.a_begin = c; a_any = true; } P.a_end = c + loopItr; }
         else { if (!b_any) { P.b_begin = c; b_any = true; } P.b_end = c + 8; }
         if (loopItr > 8 && c + 2 * unroll > W - kMargin) loopItr = 8;
         c += loopItr;
@@ -609,6 +618,8 @@ struct raisr_hip_ctx {
     // shared small tables
     uint2* d_tab14 = nullptr;
     uint16_t* d_lut = nullptr;
+    uint16_t* d_tab16 = nullptr;                // rcpph T, rsqrtph T0, T1
+    GaussW16 gauss16{};
     // scratch planes
     uint16_t* d_lr[2] = {nullptr, nullptr};     // LR plane per pass (u16)
     uint16_t* d_hash[2] = {nullptr, nullptr};
@@ -713,6 +724,36 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     timer_end(c, s, slot);
 }
 
+// one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
+template <typename TOut>
+void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+{
+    const int W = c->passW[pass], H = c->passH[pass];
+    PassParams P = make_pass(c, pass, W, H);
+    const ModelDev& m = c->model[pass];
+    Pass16 Q{};
+    const int rows = m.h.hashkeys * m.h.pixel_types;
+    Q.bank16 = (const uint32_t*)((const char*)m.blob + kBlobHeader + blob_f32_bytes(rows));
+    Q.tab16 = c->d_tab16;
+    Q.qangle = m.h.qangle16; Q.qs0 = m.h.qstr16[0]; Q.qs1 = m.h.qstr16[1]; Q.qc0 = m.h.qcoh16[0]; Q.qc1 = m.h.qcoh16[1];
+    { volatile float nf = 1.0f / (255.0f * 255.0f * 2.0f * 2.0f); Q.nf = nf; }
+    Q.c_avx = (W - 1) - ((W - 1) % 32) + 1;
+    int slot;
+    if (P.c_final > kMargin && H > 2 * kMargin) {
+        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
+        timer_begin(c, "k_hash16", s, slot);
+        hipLaunchKernelGGL((k_hash16<4>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
+        timer_end(c, s, slot);
+        timer_begin(c, "k_filter16", s, slot);
+        hipLaunchKernelGGL(k_filter16, gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
+        timer_end(c, s, slot);
+    }
+    dim3 gb((W + 63) / 64, (H + 15) / 16);
+    timer_begin(c, "k_blend16", s, slot);
+    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
+}
+
 void free_scratch(raisr_hip_ctx* c)
 {
     for (int i = 0; i < 2; i++) {
@@ -759,6 +800,18 @@ int raisr_hip_create(raisr_hip_ctx** out, int device_index)
     HIP_TRY(hipMalloc((void**)&c->d_lut, lut.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(c->d_tab14, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> t16(3072);
+    for (int i = 0; i < 1024; i++) { t16[i] = X86_RCPPH_T[i]; t16[1024 + i] = X86_RSQRTPH_T0[i]; t16[2048 + i] = X86_RSQRTPH_T1[i]; }
+    HIP_TRY(hipMalloc((void**)&c->d_tab16, t16.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(c->d_tab16, t16.data(), t16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {   // un-normalised Gaussian in binary16, (fp16)literal (Raisr_globals.h:267-278)
+        for (int i = 0; i < 11; i++)
+            for (int k = 0; k < 11; k++) {
+                const _Float16 wv = (_Float16)kGaussQ[i < 6 ? i : 10 - i][k < 6 ? k : 10 - k];
+                uint16_t u; memcpy(&u, &wv, 2);
+                c->gauss16.wT[k][i] = (uint32_t)u | ((uint32_t)u << 16);
+            }
+    }
     *out = c;
     return RAISR_HIP_OK;
 }
@@ -773,6 +826,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     for (int i = 0; i < 2; i++) if (c->model[i].blob) hipFree(c->model[i].blob);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_tab16) (void)hipFree(c->d_tab16);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -782,24 +836,39 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
 size_t raisr_hip_model_blob_bytes(int hashkeys, int pixel_types)
 {
     if (hashkeys <= 0 || pixel_types <= 0) return 0;
-    return (size_t)kBlobHeader + (size_t)hashkeys * pixel_types * kTapsPad * sizeof(float);
+    const int rows = hashkeys * pixel_types;
+    return (size_t)kBlobHeader + blob_f32_bytes(rows) + blob_f16_bytes(rows);
 }
 
 int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, int pixel_types,
-                              const float qstr[2], const float qcoh[2], int quant_angle)
+                              const double qstr[2], const double qcoh[2], int quant_angle)
 {
     if (!host_blob || !bank || !qstr || !qcoh) return fail(RAISR_HIP_EINVAL, "null argument");
     if (hashkeys <= 0 || hashkeys > 255 || (pixel_types != 1 && pixel_types != 4) || quant_angle <= 0)
         return fail(RAISR_HIP_EINVAL, "unsupported model geometry");
+    auto hbits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
     BlobHeader h{};
     h.magic = kBlobMagic; h.hashkeys = hashkeys; h.pixel_types = pixel_types; h.quant_angle = quant_angle;
     h.qangle = (float)quant_angle / 3.141592653f;           // gQAngle, Raisr.cpp:1553
-    h.qstr[0] = qstr[0]; h.qstr[1] = qstr[1]; h.qcoh[0] = qcoh[0]; h.qcoh[1] = qcoh[1];
+    for (int i = 0; i < 2; i++) {
+        h.qstr[i] = (float)qstr[i]; h.qcoh[i] = (float)qcoh[i];                 // (float)stod(token), Raisr.cpp:377,413
+        h.qstr16[i] = hbits((_Float16)qstr[i]); h.qcoh16[i] = hbits((_Float16)qcoh[i]);   // (_Float16)stod(token)
+    }
+    h.qangle16 = hbits((_Float16)h.qangle);                 // _mm512_set1_ph(gQAngle)
     memcpy(host_blob, &h, sizeof h);
-    float* dst = (float*)((char*)host_blob + kBlobHeader);
     const size_t rows = (size_t)hashkeys * pixel_types;
-    memset(dst, 0, rows * kTapsPad * sizeof(float));
+    float* dst = (float*)((char*)host_blob + kBlobHeader);
+    memset(dst, 0, blob_f32_bytes((int)rows));
     for (size_t r = 0; r < rows; r++) memcpy(dst + r * kTapsPad, bank + r * kTaps, kTaps * sizeof(float));
+    // binary16 bank (Raisr.cpp:344-350: currentfilter[j] = (_Float16)weight), lane-pair interleaved
+    uint16_t* d16 = (uint16_t*)((char*)host_blob + kBlobHeader + blob_f32_bytes((int)rows));
+    for (size_t r = 0; r < rows; r++)
+        for (int ch = 0; ch < 4; ch++)
+            for (int l = 0; l < 16; l++) {
+                const int k0 = 32 * ch + l, k1 = k0 + 16;
+                d16[(r * 64 + ch * 16 + l) * 2 + 0] = k0 < kTaps ? hbits((_Float16)bank[r * kTaps + k0]) : (uint16_t)0;
+                d16[(r * 64 + ch * 16 + l) * 2 + 1] = k1 < kTaps ? hbits((_Float16)bank[r * kTaps + k1]) : (uint16_t)0;
+            }
     return RAISR_HIP_OK;
 }
 
@@ -823,7 +892,7 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
 }
 
 int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,
-                        const float qstr[2], const float qcoh[2], int quant_angle)
+                        const double qstr[2], const double qcoh[2], int quant_angle)
 {
     if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
     const size_t bytes = raisr_hip_model_blob_bytes(hashkeys, pixel_types);
@@ -847,8 +916,11 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     if (cfg->passes != 1 && cfg->passes != 2) return fail(RAISR_HIP_EINVAL, "passes must be 1 or 2");
     if (cfg->in_width <= 0 || cfg->in_height <= 0 || cfg->out_width <= 0 || cfg->out_height <= 0)
         return fail(RAISR_HIP_EINVAL, "bad plane size");
-    if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512)
-        return fail(RAISR_HIP_EINVAL, "hash variant not supported by this build");
+    if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512 &&
+        cfg->hash_variant != RAISR_HIP_HASH_FP16)
+        return fail(RAISR_HIP_EINVAL, "unknown hash variant");
+    if (cfg->hash_variant == RAISR_HIP_HASH_FP16 && cfg->bits != 8)
+        return fail(RAISR_HIP_EINVAL, "the binary16 pipeline supports 8-bit content only");
     if (cfg->blending != RAISR_HIP_BLEND_COUNT) return fail(RAISR_HIP_EINVAL, "blending mode not supported by this build");
     if (!c->model[0].valid || (cfg->passes == 2 && !c->model[1].valid)) return fail(RAISR_HIP_ESTATE, "model not set");
     for (int p = 0; p < cfg->passes; p++)
@@ -897,14 +969,18 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
         if (bps == 1) launch_resize<uint8_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
         else launch_resize<uint16_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
     }
+    const bool fp16 = g.hash_variant == RAISR_HIP_HASH_FP16;
     if (g.passes == 1) {
-        if (bps == 1) run_pass<uint8_t>(c, s, 0, d_out, ope); else run_pass<uint16_t>(c, s, 0, d_out, ope);
+        if (fp16) run_pass16<uint8_t>(c, s, 0, d_out, ope);
+        else if (bps == 1) run_pass<uint8_t>(c, s, 0, d_out, ope); else run_pass<uint16_t>(c, s, 0, d_out, ope);
     } else {
-        run_pass<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
+        if (fp16) run_pass16<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
+        else run_pass<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
         // pass-2 LR: the intermediate, upscaled now if mode 2 (Raisr.cpp:945-975)
         ResizeParams R = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
         launch_resize<uint16_t, uint16_t>(c, s, c->d_mid, c->d_lr[1], R, "k_resize");
-        if (bps == 1) run_pass<uint8_t>(c, s, 1, d_out, ope); else run_pass<uint16_t>(c, s, 1, d_out, ope);
+        if (fp16) run_pass16<uint8_t>(c, s, 1, d_out, ope);
+        else if (bps == 1) run_pass<uint8_t>(c, s, 1, d_out, ope); else run_pass<uint16_t>(c, s, 1, d_out, ope);
     }
     HIP_TRY(hipGetLastError());
     return RAISR_HIP_OK;

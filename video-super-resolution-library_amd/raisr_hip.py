@@ -182,8 +182,8 @@ def read_model_folder(folder, bits, pass_no):
     if len(raw) - 16 != hk * pt * rows * 4 or rows != 121:
         raise ValueError("hashtable corrupted")
     bank = np.frombuffer(raw[16:], dtype="<f4").reshape(hk, pt, rows).copy()
-    qstr = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_strbin" + sfx)).read().split()], np.float32)
-    qcoh = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_cohbin" + sfx)).read().split()], np.float32)
+    qstr = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_strbin" + sfx)).read().split()], np.float64)
+    qcoh = np.array([float(t) for t in open(os.path.join(folder, "Qfactor_cohbin" + sfx)).read().split()], np.float64)
     qa = int(open(os.path.join(folder, "config")).readline().split()[0])
     return bank, qstr, qcoh, qa
 
@@ -194,7 +194,7 @@ def pack_model_blob(bank, qstr, qcoh, quant_angle):
     n = lib().raisr_hip_model_blob_bytes(hk, pt)
     blob = np.zeros(n, np.uint8)
     bank = np.ascontiguousarray(bank, np.float32)
-    qstr = np.ascontiguousarray(qstr, np.float32); qcoh = np.ascontiguousarray(qcoh, np.float32)
+    qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
     _check(lib().raisr_hip_pack_model_blob(blob.ctypes.data, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
                                            quant_angle), "pack_model_blob")
     return blob
@@ -226,7 +226,7 @@ class RaisrDevice:
 
     def set_model(self, pass_index, bank, qstr, qcoh, quant_angle):
         bank = np.ascontiguousarray(bank, np.float32)
-        qstr = np.ascontiguousarray(qstr, np.float32); qcoh = np.ascontiguousarray(qcoh, np.float32)
+        qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
         hk, pt, _ = bank.shape
         _check(lib().raisr_hip_set_model(self._h, pass_index, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
                                          quant_angle), "raisr_hip_set_model")
