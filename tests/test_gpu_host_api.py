@@ -1,0 +1,89 @@
+"""-m gpu: the reference plugin API (RNLHandler_*) end to end on the GPU -- vf_raisr's call protocol,
+chroma planes, row steps larger than the width, repeated frames, re-init -- against the oracle."""
+import numpy as np
+import pytest
+
+from common import folder, oracle_y
+
+pytestmark = pytest.mark.gpu
+
+
+def _strided(a, pad):
+    buf = np.zeros((a.shape[0], a.shape[1] + pad), a.dtype)
+    buf[:, :a.shape[1]] = a
+    return buf[:, :a.shape[1]]
+
+
+@pytest.mark.parametrize("bits,asm,passes,mode", [(8, 2, 1, 1), (8, 5, 2, 2), (10, 2, 1, 1), (8, 6, 2, 1)])
+def test_rnlhandler_protocol_yuv420(bits, asm, passes, mode):
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h = 160, 90
+    fold = "filters_2x/filters_highres" if not (asm == 5 and mode == 2) else "filters_2x/filters_denoise"
+    dt = np.uint8 if bits == 8 else np.uint16
+    ys = [synth.natural_y(w, h, bits, seed=s) for s in (1, 2, 3)]
+    u = (synth.random_y(w // 2, h // 2, bits, seed=8)).astype(dt)
+    v = (synth.random_y(w // 2, h // 2, bits, seed=9)).astype(dt)
+    # planes with step > width*bytes, as FFmpeg hands them over (vf_raisr.c:262-285)
+    yin = [_strided(y, 24) for y in ys]
+    uin, vin = _strided(u, 8), _strided(v, 8)
+    oy = _strided(np.zeros((2 * h, 2 * w), dt), 40)
+    ou, ov = _strided(np.zeros((h, w), dt), 16), _strided(np.zeros((h, w), dt), 16)
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, bits, R.VideoRange, 20, asm, passes, mode) == 0
+    try:
+        assert R.RNLHandler_SetRes((yin[0], uin, vin), (oy, ou, ov)) == 0
+        ref_asm = 2 if asm == 6 else asm
+        for y, ysrc in zip(yin, ys):
+            assert R.RNLHandler_Process((y, uin, vin), (oy, ou, ov), R.CountOfBitsChanged) == 0
+            ref = oracle_y(ysrc, ("x", fold, (2, 1), bits, passes, mode, ref_asm, False))
+            assert np.array_equal(oy, ref)
+            assert np.array_equal(ou, O.resize(u, w, h).astype(dt)) and np.array_equal(ov, O.resize(v, w, h).astype(dt))
+        assert R.RNLHandler_Process((yin[0], uin, vin), (oy, ou, ov), R.Randomness) == R.RNLErrorBadParameter
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+    # re-init with a different geometry / ratio in the same process (the reference is a process-global singleton too)
+    y = synth.natural_y(96, 64, 8, seed=4)
+    c = synth.chroma(48, 32, 8)
+    oy2, ou2, ov2 = R.upscale_frame_host(y, c, c, folder("filters_1.5x/filters_highres"), ratio=1.5, bits=8, asm_type=R.AVX512)
+    assert np.array_equal(oy2, oracle_y(y, ("x", "filters_1.5x/filters_highres", (3, 2), 8, 1, 1, 2, False)))
+    assert oy2.shape == (96, 144) and np.all(ou2 == 128)
+
+
+def test_model_blob_device_path_matches_file_path():
+    """rank-0-reads / others-receive-the-blob path: a context fed through set_model_blob_device gives
+    the same output as one fed from the files."""
+    import raisr_hip as R
+    import synth
+    import torch
+    y = synth.natural_y(128, 72, 8, seed=6)
+    outs = []
+    for use_blob in (False, True):
+        dev = R.RaisrDevice(0)
+        if use_blob:
+            for p in range(2):
+                bank, qs, qc, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, p + 1)
+                blob = torch.from_numpy(R.pack_model_blob(bank, qs, qc, qa)).cuda()
+                dev.set_model_blob_device(p, blob.data_ptr(), blob.numel())
+        else:
+            dev.set_model_from_folder(folder("filters_2x/filters_highres"), 8, 2)
+        dev.configure(128, 72, 256, 144, bits=8, passes=2, mode=1)
+        out = np.zeros((144, 256), np.uint8)
+        dev.process_host(y, out)
+        dev.close()
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_loud_failures():
+    import raisr_hip as R
+    dev = R.RaisrDevice(0)
+    with pytest.raises(RuntimeError, match="model not set"):
+        dev.configure(64, 64, 128, 128)
+    dev.set_model_from_folder(folder("filters_2x/filters_highres"), 8, 1)
+    with pytest.raises(RuntimeError, match="pixel types"):
+        dev.configure(64, 64, 96, 96, ratio2=False)
+    with pytest.raises(RuntimeError, match="8-bit"):
+        dev.configure(64, 64, 128, 128, bits=10, hash_variant=R.HASH_FP16)
+    dev.close()

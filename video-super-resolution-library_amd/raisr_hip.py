@@ -59,6 +59,14 @@ def lib():
         if not os.path.exists(_SO):
             raise RuntimeError(f"{_SO} is missing: build it with `make -C {_HERE}` (hipcc, gfx950). "
                                "There is no CPU fallback.")
+        # libraisr_hip.so and PyTorch-ROCm both need "libamdhip64.so.7"; the dynamic loader keeps one
+        # copy per SONAME, so whichever is loaded first serves both.  PyTorch only works on its own
+        # bundled runtime, hence load it first whenever it is installed (tensors' data_ptr()s and
+        # streams are then valid in this library because there is exactly one HIP runtime).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(_SO)
         L.raisr_hip_last_error.restype = ctypes.c_char_p
         L.raisr_hip_version.restype = ctypes.c_char_p
