@@ -86,6 +86,11 @@ int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const
 /* Geometry / resources ------------------------------------------------------------------------ */
 int raisr_hip_configure(raisr_hip_ctx *ctx, const raisr_hip_config *cfg);
 
+/* BlendingMode is a per-frame argument of RNLProcess (Raisr.h:28-30): switch it without reallocating.
+ * Randomness never writes the pixels [c_final, W-6) of row H-7 (reference behaviour): the device output
+ * plane keeps its previous contents there. */
+int raisr_hip_set_blending(raisr_hip_ctx *ctx, int blending);
+
 /* Hot path ------------------------------------------------------------------------------------
  * Device-resident planes.  Pitches are in BYTES.  `stream` is a hipStream_t (NULL = the
  * context's own stream).  Asynchronous: returns after enqueueing. */

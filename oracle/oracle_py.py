@@ -171,10 +171,10 @@ def make_pass16(folder, bits, pass_no, full_range=False, blending=BLEND_COUNT):
     return p
 
 
-def run_pass16(lr, p, dumps=False):
+def run_pass16(lr, p, dumps=False, preset=None):
     lr = _u16(lr)
     h, w = lr.shape
-    out = np.zeros((h, w), dtype=np.uint16)
+    out = np.zeros((h, w), dtype=np.uint16) if preset is None else _u16(preset).copy()
     hd = np.empty((h, w), dtype=np.int32) if dumps else None
     hr = np.empty((h, w), dtype=np.uint16) if dumps else None
     lib().ora16_pass(lr.ctypes.data_as(ctypes.c_void_p), w, h, ctypes.byref(p), out.ctypes.data_as(ctypes.c_void_p),

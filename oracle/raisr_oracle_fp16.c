@@ -272,6 +272,13 @@ void ora16_pass(const uint16_t *lr, int W, int H, const ora16_pass_t *P, uint16_
     int c_end = LM;
     { int loopItr = 32, c = LM; while (c + loopItr <= W - LM) { if (loopItr > 8 && c + 64 > W - LM) loopItr = 8; c += loopItr; } c_end = c; }
 
+    const int randomness = P->blending == 1;
+    if (randomness)      /* everything the loop below does not write is the unclamped LR copy, except the never-written
+                          * pixels [c_end, W-6) of row H-7 (left as the caller preset them) */
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++)
+                if (!((H >= 2 * LM + 1) && r == H - LM - 1 && c >= c_end && c < W - LM)) out[(size_t)r * W + c] = lr[(size_t)r * W + c];
+
     #pragma omp parallel for schedule(dynamic, 2)
     for (int r = LM; r < H - LM; r++)
         for (int c = LM; c < c_end; c++) {
@@ -282,8 +289,25 @@ void ora16_pass(const uint16_t *lr, int W, int H, const ora16_pass_t *P, uint16_
             h16 v = dot_patch_h(L, W, r, c, P->bank + ((size_t)h * P->pixel_types + t) * TAPS);
             size_t idx = (size_t)r * W + c;
             if (hash_dump) hash_dump[idx] = h;
-            if (h_lt(hlo, v) && h_lt(v, hhi)) HR[idx] = v;          /* Raisr.cpp:1188-1192 */
+            h16 cur = L[idx];
+            if (h_lt(hlo, v) && h_lt(v, hhi)) { HR[idx] = v; cur = v; }   /* Raisr.cpp:1188-1192 */
+            if (randomness) {                                        /* Raisr.cpp:1203-1242, fp32 arithmetic (:1224-1230) */
+                int census = 0;
+                for (int i = -1; i <= 1; i++)
+                    for (int j = -1; j <= 1; j++)
+                        if (i || j) census += h_lt(L[(size_t)(r + i) * W + c + j], L[idx]);
+                float weight = (float)census / 8.0f;
+                float val = weight * h2f(cur) + (1.0f - weight) * h2f(L[idx]);
+                val = (float)((double)val + 0.5);
+                float cl = val < (float)P->lo ? (float)P->lo : (val > (float)P->hi ? (float)P->hi : val);
+                out[idx] = (uint16_t)cl;
+            }
         }
+    if (randomness) {
+        if (hr_dump) memcpy(hr_dump, HR, n * sizeof(h16));
+        free(L); free(HR);
+        return;
+    }
 
     for (int c = 0; c < W; c++) { out[c] = lr[c]; out[(size_t)(H - 1) * W + c] = lr[(size_t)(H - 1) * W + c]; }
     for (int r = 0; r < H; r++) { out[(size_t)r * W] = lr[(size_t)r * W]; out[(size_t)r * W + W - 1] = lr[(size_t)r * W + W - 1]; }

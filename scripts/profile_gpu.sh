@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
+# Output goes to gpurun_out/prof_<tag>/ ; summarise afterwards with scripts/summarize_profiles.py.
+# PMC passes are separate runs with --kernel-trace only (gpurun refuses pmc + sys-trace combos).
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python $ROOT/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 10 --warmup 2 > "$OUT/stats.log" 2>&1
+$B --steps 10 --warmup 2 > "$OUT/bench_events.json" 2> "$OUT/bench_events.err"
+PMC="$B --steps 2 --warmup 1 --lanes 1 --no-kernel-timing"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS -d "$OUT/pmc_sq" -- $PMC > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d "$OUT/pmc_lds" -- $PMC > "$OUT/pmc_lds.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $PMC > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $PMC > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -- $PMC > "$OUT/pmc_l2.log" 2>&1
+echo done

@@ -40,7 +40,8 @@ def test_rnlhandler_protocol_yuv420(bits, asm, passes, mode):
             ref = oracle_y(ysrc, ("x", fold, (2, 1), bits, passes, mode, ref_asm, False))
             assert np.array_equal(oy, ref)
             assert np.array_equal(ou, O.resize(u, w, h).astype(dt)) and np.array_equal(ov, O.resize(v, w, h).astype(dt))
-        assert R.RNLHandler_Process((yin[0], uin, vin), (oy, ou, ov), R.Randomness) == R.RNLErrorBadParameter
+        assert R.RNLHandler_Process((yin[0], uin, vin), (oy, ou, ov), R.Randomness) == 0
+        assert R.RNLHandler_Process((yin[0], uin, vin), (oy, ou, ov), 3) == R.RNLErrorBadParameter
     finally:
         assert R.RNLHandler_Deinit() == 0
     # re-init with a different geometry / ratio in the same process (the reference is a process-global singleton too)

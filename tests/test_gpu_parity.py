@@ -47,3 +47,45 @@ def test_y_bit_exact(case, size):
         got, _ = _gpu(y, case)
         bad = np.argwhere(ref != got)
         assert bad.size == 0, f"{case[0]} {name} {w}x{h}: {len(bad)} mismatching pixels, first at {bad[:5].tolist()}"
+
+
+@pytest.mark.parametrize("asm,passes", [(2, 1), (1, 1), (5, 1), (2, 2)])
+def test_randomness_blending_bit_exact(asm, passes):
+    """BlendingMode Randomness: blended filtered zone, unclamped LR elsewhere, and the
+    never-written pixels [c_final, W-6) of row H-7 keep the caller's bytes."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    fold = folder("filters_2x/filters_highres")
+    for w, h in ((96, 64), (134, 50)):
+        for name in ("natural", "random"):
+            y = synth.FRAME_KINDS[name](w, h, 8)
+            ow, oh = 2 * w, 2 * h
+            lr = O.resize(y, ow, oh)
+            preset = np.full((oh, ow), 77, np.uint8)
+            if asm == 5:
+                p1 = O.make_pass16(fold, 8, 1, blending=O.BLEND_RANDOMNESS)
+                p2 = O.make_pass16(fold, 8, 2, blending=O.BLEND_RANDOMNESS)
+                run = lambda a, p, pre: O.run_pass16(a, p, preset=pre)
+            else:
+                p1 = O.make_pass(O.Model(fold, 8, 1), 8, False, asm, O.BLEND_RANDOMNESS)
+                p2 = O.make_pass(O.Model(fold, 8, 2), 8, False, asm, O.BLEND_RANDOMNESS)
+                run = lambda a, p, pre: O.run_pass(a, p, preset=pre)
+            if passes == 1:
+                ref = run(lr, p1, preset)
+            else:
+                ref = run(run(lr, p1, np.zeros((oh, ow), np.uint16)), p2, preset)
+            dev = R.RaisrDevice(0)
+            dev.set_model_from_folder(fold, 8, passes)
+            dev.configure(w, h, ow, oh, bits=8, passes=passes, mode=1, hash_variant=asm, blending=R.BLEND_RANDOMNESS)
+            out = preset.copy()
+            dev.process_host(y, out)
+            dev.set_blending(R.BLEND_COUNT)                      # per-frame switch, as RNLProcess allows
+            out2 = np.zeros((oh, ow), np.uint8)
+            dev.process_host(y, out2)
+            dev.close()
+            assert np.array_equal(out, ref.astype(np.uint8)), (asm, passes, w, h, name, int((out != ref).sum()))
+            c_final = 6 + 8 * ((ow - 12) // 8)
+            assert np.all(out[oh - 7, c_final:ow - 6] == 77)
+            case = ("x", "filters_2x/filters_highres", (2, 1), 8, passes, 1, asm, False)
+            assert np.array_equal(out2, _oracle(y, case))

@@ -324,10 +324,8 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         return RNLErrorBadParameter;
     if (!inCb || !inCb->pData || !outCb || !outCb->pData) return RNLErrorBadParameter;
     if (!G.inited || !G.resSet || !G.ctx) return RNLErrorBadParameter;
-    if (blendingMode != CountOfBitsChanged) {
-        std::cout << "[RAISR ERROR] blending mode " << (int)blendingMode << " is not supported by the HIP backend yet." << std::endl;
-        return RNLErrorBadParameter;
-    }
+    if (blendingMode != CountOfBitsChanged && blendingMode != Randomness) return RNLErrorBadParameter;
+    if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
     const int rc = raisr_hip_process_host(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
                                           inCr->pData, inCr->step, outCr->pData, outCr->step,
                                           inCb->pData, inCb->step, outCb->pData, outCb->step,

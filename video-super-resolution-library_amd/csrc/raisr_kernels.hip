@@ -68,6 +68,7 @@ struct PassParams {
     int b_begin, b_end;          // columns hashed with the AVX2 flavour (after the AVX-512 one)
     int c_final;                 // first column that is never filtered
     int pixel_types;             // 4 (ratio 2) or 1
+    int randomness;              // 1: BlendingMode Randomness (tail re-hash candidate replaces, never keeps, the first)
     float qangle, qs0, qs1, qc0, qc1;
     const float* bank;           // [hash][type][128]
     const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(p[ch], f[16 * ch], acc);
                 const float v = tree16(acc);
                 if (v > P.lo && v < P.hi) res = v;
+                else if (P.randomness) res = center;            // Randomness blends the LAST candidate (Raisr.cpp:1196-1200,1230)
             }
             if (s == l) keep = res;                             // lane (g,l) keeps pixel column 4l+g
         }
@@ -514,6 +516,46 @@ __global__ __launch_bounds__(256) void k_blend(const uint16_t* __restrict__ lr, 
         }
         out[(size_t)y * out_pitch + x] = (TOut)iv;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blend_rand (BlendingMode Randomness): CTRandomness_AVX512_32f (Raisr_AVX512.cpp:19-35) + the inline
+// blend of processSegment (Raisr.cpp:1203-1242).  Only the filtered pixels are blended; every other
+// pixel is the unclamped LR copy, and the W-6-c_final pixels [c_final, W-6) of row H-7 are never
+// written by the reference -- they keep whatever the output buffer held.
+// The fp16 pipeline promotes to fp32 for this blend (Raisr.cpp:1224-1230), so one kernel serves both.
+// ------------------------------------------------------------------------------------------------
+template <typename TOut, bool HR16>
+__global__ __launch_bounds__(256) void k_blend_rand(const uint16_t* __restrict__ lr, const void* __restrict__ hr,
+                                                    PassParams P, TOut* __restrict__ out, int out_pitch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    const uint16_t lc = lr[(size_t)y * P.lr_pitch + x];
+    const bool zone = y >= kMargin && y < P.H - kMargin && x >= kMargin && x < P.c_final;
+    if (!zone) {
+        const bool untouched = P.H >= 2 * kMargin + 1 && y == P.H - kMargin - 1 && x >= P.c_final && x < P.W - kMargin;
+        if (!untouched) out[(size_t)y * out_pitch + x] = (TOut)lc;
+        return;
+    }
+    const float Lc = (float)lc;
+    float cur;
+    if (HR16) cur = (float)__builtin_bit_cast(_Float16, ((const uint16_t*)hr)[(size_t)y * P.hr_pitch + x]);
+    else cur = ((const float*)hr)[(size_t)y * P.hr_pitch + x];
+    int census = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            census += ((float)lr[(size_t)(y + dy) * P.lr_pitch + x + dx] < Lc);
+        }
+    const float weight = (float)census * 0.125f;                // census / 8.0f exactly
+    float val = (weight * cur) + ((1.0f - weight) * Lc);
+    val = val + 0.5f;
+    const float cl = val < P.lo ? P.lo : (val > P.hi ? P.hi : val);
+    out[(size_t)y * out_pitch + x] = (TOut)(int)cl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -613,6 +655,7 @@ struct raisr_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     raisr_hip_config cfg{};
+    int blending = RAISR_HIP_BLEND_COUNT;      // per-call BlendingMode (RNLProcess argument)
     bool configured = false;
     ModelDev model[2];
     // shared small tables
@@ -690,6 +733,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.ilo = g.clamp_lo; P.ihi = g.clamp_hi;
     column_plan(W, g.hash_variant, P);
     P.pixel_types = m.h.pixel_types;
+    P.randomness = c->blending == RAISR_HIP_BLEND_RANDOMNESS;
     P.qangle = m.h.qangle;
     P.qs0 = m.h.qstr[0]; P.qs1 = m.h.qstr[1];
     P.qc0 = m.h.qcoh[0]; P.qc1 = m.h.qcoh[1];
@@ -717,6 +761,13 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         timer_begin(c, "k_filter", s, slot);
         hipLaunchKernelGGL(k_filter, gf, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, c->d_hr[pass]);
         timer_end(c, s, slot);
+    }
+    if (P.randomness) {
+        dim3 gb((W + 63) / 64, (H + 3) / 4);
+        timer_begin(c, "k_blend_rand", s, slot);
+        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        timer_end(c, s, slot);
+        return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend", s, slot);
@@ -747,6 +798,13 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
         timer_begin(c, "k_filter16", s, slot);
         hipLaunchKernelGGL(k_filter16, gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
         timer_end(c, s, slot);
+    }
+    if (P.randomness) {
+        dim3 gr((W + 63) / 64, (H + 3) / 4);
+        timer_begin(c, "k_blend_rand", s, slot);
+        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        timer_end(c, s, slot);
+        return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend16", s, slot);
@@ -921,7 +979,8 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
         return fail(RAISR_HIP_EINVAL, "unknown hash variant");
     if (cfg->hash_variant == RAISR_HIP_HASH_FP16 && cfg->bits != 8)
         return fail(RAISR_HIP_EINVAL, "the binary16 pipeline supports 8-bit content only");
-    if (cfg->blending != RAISR_HIP_BLEND_COUNT) return fail(RAISR_HIP_EINVAL, "blending mode not supported by this build");
+    if (cfg->blending != RAISR_HIP_BLEND_COUNT && cfg->blending != RAISR_HIP_BLEND_RANDOMNESS)
+        return fail(RAISR_HIP_EINVAL, "blending must be 1 (Randomness) or 2 (CountOfBitsChanged)");
     if (!c->model[0].valid || (cfg->passes == 2 && !c->model[1].valid)) return fail(RAISR_HIP_ESTATE, "model not set");
     for (int p = 0; p < cfg->passes; p++)
         if (c->model[p].h.pixel_types != (cfg->use_pixel_type ? 4 : 1))
@@ -947,8 +1006,19 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     if (cfg->passes == 2) {
         const size_t n = (size_t)c->passW[0] * c->passH[0];
         if (hipMalloc((void**)&c->d_mid, n * sizeof(uint16_t)) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
+        HIP_TRY(hipMemset(c->d_mid, 0, n * sizeof(uint16_t)));   // pixels the Randomness pass never writes stay 0
     }
+    c->blending = cfg->blending;
     c->configured = true;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_blending(raisr_hip_ctx* c, int blending)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    if (blending != RAISR_HIP_BLEND_COUNT && blending != RAISR_HIP_BLEND_RANDOMNESS)
+        return fail(RAISR_HIP_EINVAL, "blending must be 1 (Randomness) or 2 (CountOfBitsChanged)");
+    c->blending = blending;
     return RAISR_HIP_OK;
 }
 
@@ -1039,6 +1109,8 @@ int raisr_hip_process_host(raisr_hip_ctx* c,
         HIP_TRY(hipMemcpy2DAsync(d + off_iu, (size_t)cin_w * bps, in_u, in_u_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpy2DAsync(d + off_iv, (size_t)cin_w * bps, in_v, in_v_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
     }
+    if (c->blending == RAISR_HIP_BLEND_RANDOMNESS)   // pixels the reference leaves untouched keep the caller's bytes
+        HIP_TRY(hipMemcpy2DAsync(d + off_oy, (size_t)g.out_width * bps, out_y, out_y_pitch, (size_t)g.out_width * bps, g.out_height, hipMemcpyHostToDevice, s));
     int rc = raisr_hip_process_y_device(c, d, (size_t)g.in_width * bps, d + off_oy, (size_t)g.out_width * bps, s);
     if (rc) return rc;
     if (chroma) {

@@ -87,6 +87,7 @@ def lib():
                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         L.raisr_hip_process_host.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -269,6 +270,9 @@ class RaisrDevice:
         cw, ch = (u.shape[1], u.shape[0]) if u is not None else (0, 0)
         ocw, och = (ou.shape[1], ou.shape[0]) if ou is not None else (0, 0)
         _check(lib().raisr_hip_process_host(self._h, *args, cw, ch, ocw, och), "raisr_hip_process_host")
+
+    def set_blending(self, blending):
+        _check(lib().raisr_hip_set_blending(self._h, blending), "raisr_hip_set_blending")
 
     def synchronize(self):
         _check(lib().raisr_hip_synchronize(self._h), "raisr_hip_synchronize")
