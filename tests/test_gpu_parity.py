@@ -89,3 +89,20 @@ def test_randomness_blending_bit_exact(asm, passes):
             assert np.all(out[oh - 7, c_final:ow - 6] == 77)
             case = ("x", "filters_2x/filters_highres", (2, 1), 8, passes, 1, asm, False)
             assert np.array_equal(out2, _oracle(y, case))
+
+
+@pytest.mark.parametrize("size,ratio,fold", [((31, 29), (2, 1), "filters_2x/filters_highres"), ((7, 7), (2, 1), "filters_2x/filters_highres"),
+                                             ((13, 40), (2, 1), "filters_2x/filters_lowres"), ((86, 50), (3, 2), "filters_1.5x/filters_highres"),
+                                             ((20, 12), (3, 2), "filters_1.5x/filters_denoise"), ((300, 8), (2, 1), "filters_2x/filters_highres")],
+                         ids=lambda v: str(v).replace(" ", ""))
+def test_small_and_odd_geometries(size, ratio, fold):
+    """Ragged sizes: frames narrower than one 16-column chunk (nothing is filtered in AVX-512 mode,
+    Raisr.cpp:1066), heights barely above the 12-row margin, odd output sizes."""
+    import synth
+    w, h = size
+    for asm in (1, 2, 5):
+        case = ("x", fold, ratio, 8, 1, 1, asm, False)
+        y = synth.random_y(w, h, 8, seed=w * 100 + h)
+        ref = _oracle(y, case)
+        got, _ = _gpu(y, case)
+        assert np.array_equal(ref, got), (size, asm, int((ref != got).sum()))
