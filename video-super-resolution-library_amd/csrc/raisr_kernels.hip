@@ -158,6 +158,15 @@ __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, T
     }
 }
 
+// same-size case of the cheap upscale (two-pass mode 2 runs pass 1 at input size, Raisr.cpp:960-975): widen/copy
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < R.dw && y < R.dh) dst[(size_t)y * R.dpitch + x] = (TOut)src[(size_t)y * R.spitch + x];
+}
+
 // ------------------------------------------------------------------------------------------------
 // hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
 // (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
@@ -254,7 +263,7 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
 __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
 template <int R>
-__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
+__global__ __launch_bounds__(256, 4) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
                                                   uint16_t* __restrict__ hash_out)
 {
     constexpr int TH = 4 * R;
@@ -401,43 +410,60 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
         off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
     }
 
+    // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
+    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P.bank), 0, 216 * 4 * kTapsPad * (int)sizeof(float), 0x00020000);
+    const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
+    const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
+
 #pragma unroll 1
     for (int row = 0; row < 4; row++) {
         const int prow = 4 * w + row;
         const int r = r0 + prow;
+        const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kTapsPad * 4) : 0u;
+        // LDS byte addresses of this lane's 8 taps (and the centre pixel) for step 0; step s adds the immediate 16*s
+        const char* tap[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off[ch]);
+        const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
+#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
+#define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         float keep = 0.0f;
+        bool anyB = false;
 #pragma unroll 4
-        for (int s = 0; s < 16; s++) {
-            const int pcol = 4 * s + g;
-            const int c = c0 + pcol;
-            const unsigned hh = sH[prow * TW + pcol];
-            const unsigned hA = hh & 0xFFu, hB = hh >> 8;
-            const int base = prow * LW + pcol;                  // patch top-left in the tile
-            const float center = sL[base + 5 * LW + 5];
-            const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
-            float p[8];
-#pragma unroll
-            for (int ch = 0; ch < 8; ch++) p[ch] = sL[base + off[ch]];
-            float res = center;
+        for (int s = 0; s < 16; s++) {          // unroll 4 measured best (1: same, 8/16: slower -- code size / occupancy)
+            const unsigned hh = sH[prow * TW + 4 * s + g];
+            const unsigned hA = hh & 0xFFu;
+            anyB |= (hh >> 8) != 0xFFu;
+            float res = RAISR_LDS_F(ctr, s);
             if (hA != 0xFFu) {
-                const float* f = P.bank + ((size_t)(hA * P.pixel_types + t) * kTapsPad + l);
-                float acc = p[0] * f[0];
+                const unsigned voff = hA * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
+                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(p[ch], f[16 * ch], acc);
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
                 const float v = tree16(acc);
                 if (v > P.lo && v < P.hi) res = v;
-            }
-            if (hB != 0xFFu) {                                  // tail columns: AVX2 re-hash, keep-first-if-rejected
-                const float* f = P.bank + ((size_t)(hB * P.pixel_types + t) * kTapsPad + l);
-                float acc = p[0] * f[0];
-#pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(p[ch], f[16 * ch], acc);
-                const float v = tree16(acc);
-                if (v > P.lo && v < P.hi) res = v;
-                else if (P.randomness) res = center;            // Randomness blends the LAST candidate (Raisr.cpp:1196-1200,1230)
             }
             if (s == l) keep = res;                             // lane (g,l) keeps pixel column 4l+g
         }
+        if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
+#pragma unroll 1                                                 //  Randomness blends the last candidate instead)
+            for (int s = 0; s < 16; s++) {
+                const unsigned hB = sH[prow * TW + 4 * s + g] >> 8;
+                if (hB == 0xFFu) continue;
+                const unsigned voff = hB * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
+                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                const float v = tree16(acc);
+                if (s == l) {
+                    if (v > P.lo && v < P.hi) keep = v;
+                    else if (P.randomness) keep = RAISR_LDS_F(ctr, s);
+                }
+            }
+        }
+#undef RAISR_LDS_F
+#undef RAISR_BANK_F
         const int c = c0 + 4 * l + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
@@ -715,6 +741,9 @@ void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, 
     if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
         dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
         hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else if (R.dw == R.sw && R.dh == R.sh) {
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_copy<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else {
         dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
         hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
@@ -751,11 +780,10 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     PassParams P = make_pass(c, pass, W, H);
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
-        static const int R = []{ const char* e = getenv("RAISR_HIP_HASH_R"); return (e && atoi(e) == 8) ? 8 : 4; }();
+        constexpr int R = 4;        // rows per lane; 8 measured slower (136 VGPRs -> 3 waves/SIMD)
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         timer_begin(c, "k_hash", s, slot);
-        if (R == 8) hipLaunchKernelGGL((k_hash<8>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
-        else hipLaunchKernelGGL((k_hash<4>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
+        hipLaunchKernelGGL((k_hash<R>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
         timer_end(c, s, slot);
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         timer_begin(c, "k_filter", s, slot);
@@ -1007,6 +1035,7 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
         const size_t n = (size_t)c->passW[0] * c->passH[0];
         if (hipMalloc((void**)&c->d_mid, n * sizeof(uint16_t)) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
         HIP_TRY(hipMemset(c->d_mid, 0, n * sizeof(uint16_t)));   // pixels the Randomness pass never writes stay 0
+        HIP_TRY(hipMemset(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * sizeof(uint16_t)));
     }
     c->blending = cfg->blending;
     c->configured = true;
@@ -1044,11 +1073,16 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
         if (fp16) run_pass16<uint8_t>(c, s, 0, d_out, ope);
         else if (bps == 1) run_pass<uint8_t>(c, s, 0, d_out, ope); else run_pass<uint16_t>(c, s, 0, d_out, ope);
     } else {
-        if (fp16) run_pass16<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
-        else run_pass<uint16_t>(c, s, 0, c->d_mid, c->passW[0]);
-        // pass-2 LR: the intermediate, upscaled now if mode 2 (Raisr.cpp:945-975)
-        ResizeParams R = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
-        launch_resize<uint16_t, uint16_t>(c, s, c->d_mid, c->d_lr[1], R, "k_resize");
+        // pass 1 writes the 8/10-bit intermediate (Raisr.cpp:927-934).  When both passes run at output size
+        // (mode 1) the intermediate IS pass 2's LR plane; in mode 2 it is upscaled now (Raisr.cpp:945-975).
+        const bool same = c->passW[0] == c->passW[1] && c->passH[0] == c->passH[1];
+        uint16_t* mid = same ? c->d_lr[1] : c->d_mid;
+        if (fp16) run_pass16<uint16_t>(c, s, 0, mid, c->passW[0]);
+        else run_pass<uint16_t>(c, s, 0, mid, c->passW[0]);
+        if (!same) {
+            ResizeParams R = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
+            launch_resize<uint16_t, uint16_t>(c, s, c->d_mid, c->d_lr[1], R, "k_resize");
+        }
         if (fp16) run_pass16<uint8_t>(c, s, 1, d_out, ope);
         else if (bps == 1) run_pass<uint8_t>(c, s, 1, d_out, ope); else run_pass<uint16_t>(c, s, 1, d_out, ope);
     }
