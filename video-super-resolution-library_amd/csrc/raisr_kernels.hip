@@ -680,6 +680,7 @@ void column_plan(int W, int hash_variant, PassParams& P)
 struct raisr_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // chroma lane of raisr_hip_process_host (overlaps the Y path)
     raisr_hip_config cfg{};
     int blending = RAISR_HIP_BLEND_COUNT;      // per-call BlendingMode (RNLProcess argument)
     bool configured = false;
@@ -877,6 +878,7 @@ int raisr_hip_create(raisr_hip_ctx** out, int device_index)
     raisr_hip_ctx* c = new raisr_hip_ctx();
     c->device = device_index;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     // small shared tables
     std::vector<uint2> tab(128);
     for (int i = 0; i < 64; i++) { tab[i] = make_uint2(X86_RCP14_C0[i], X86_RCP14_C1[i]); tab[64 + i] = make_uint2(X86_RSQRT14_C0[i], X86_RSQRT14_C1[i]); }
@@ -916,6 +918,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -1137,28 +1140,27 @@ int raisr_hip_process_host(raisr_hip_ctx* c,
         c->d_stage_bytes = total;
     }
     char* d = (char*)c->d_stage;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->stream, s2 = c->stream2;
+    // Y: upload, RAISR passes, download on the context stream; chroma (plain cheap upscale, Raisr.cpp:1373-1388)
+    // runs on a second stream so its PCIe transfers overlap the Y kernels.
     HIP_TRY(hipMemcpy2DAsync(d, (size_t)g.in_width * bps, in_y, in_y_pitch, (size_t)g.in_width * bps, g.in_height, hipMemcpyHostToDevice, s));
-    if (chroma) {
-        HIP_TRY(hipMemcpy2DAsync(d + off_iu, (size_t)cin_w * bps, in_u, in_u_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(d + off_iv, (size_t)cin_w * bps, in_v, in_v_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s));
-    }
     if (c->blending == RAISR_HIP_BLEND_RANDOMNESS)   // pixels the reference leaves untouched keep the caller's bytes
         HIP_TRY(hipMemcpy2DAsync(d + off_oy, (size_t)g.out_width * bps, out_y, out_y_pitch, (size_t)g.out_width * bps, g.out_height, hipMemcpyHostToDevice, s));
     int rc = raisr_hip_process_y_device(c, d, (size_t)g.in_width * bps, d + off_oy, (size_t)g.out_width * bps, s);
     if (rc) return rc;
     if (chroma) {
-        rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, (size_t)cin_w * bps, d + off_ou, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s);
+        HIP_TRY(hipMemcpy2DAsync(d + off_iu, (size_t)cin_w * bps, in_u, in_u_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s2));
+        HIP_TRY(hipMemcpy2DAsync(d + off_iv, (size_t)cin_w * bps, in_v, in_v_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s2));
+        rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, (size_t)cin_w * bps, d + off_ou, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s2);
         if (rc) return rc;
-        rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, (size_t)cin_w * bps, d + off_ov, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s);
+        rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, (size_t)cin_w * bps, d + off_ov, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s2);
         if (rc) return rc;
+        HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s2));
+        HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s2));
     }
     HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy, (size_t)g.out_width * bps, (size_t)g.out_width * bps, g.out_height, hipMemcpyDeviceToHost, s));
-    if (chroma) {
-        HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s));
-    }
     HIP_TRY(hipStreamSynchronize(s));
+    if (chroma) HIP_TRY(hipStreamSynchronize(s2));
     return RAISR_HIP_OK;
 }
 
