@@ -28,10 +28,10 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=16)
-    ap.add_argument("--lanes", type=int, default=4, help="frames in flight per GPU (one context+stream each)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=24)
+    ap.add_argument("--lanes", type=int, default=3, help="frames in flight per GPU (one context+stream each); 3 measured best")
     ap.add_argument("--passes", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -9,8 +9,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 10 --warmup 2 > "$OUT/stats.log" 2>&1
-$B --steps 10 --warmup 2 > "$OUT/bench_events.json" 2> "$OUT/bench_events.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 20 --warmup 3 > "$OUT/stats.log" 2>&1
+$B --steps 20 --warmup 3 > "$OUT/bench_events.json" 2> "$OUT/bench_events.err"
 PMC="$B --steps 2 --warmup 1 --lanes 1 --no-kernel-timing"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS -d "$OUT/pmc_sq" -- $PMC > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d "$OUT/pmc_lds" -- $PMC > "$OUT/pmc_lds.log" 2>&1

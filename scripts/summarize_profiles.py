@@ -23,7 +23,7 @@ def short(name):
     return name[:60]
 
 
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps 10 --warmup 2` (1080p->4K 2x, highres, 1-pass, 4 lanes)", ""]
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --steps 20 --warmup 3` (1080p->4K 2x, highres, 1-pass, 3 lanes x 24 frames/step)", ""]
 f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if f:
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]

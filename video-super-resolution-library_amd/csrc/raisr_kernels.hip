@@ -171,32 +171,43 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 // hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
 // (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
 // ------------------------------------------------------------------------------------------------
-// sqrt14(v) = VRCP14(VRSQRT14(v)).  Fast path: v normal, positive and finite (then both table
-// evaluations stay in the normal range: the rsqrt14 result has a biased exponent in [62,190]) and
-// v == +0 (-> rcp14(+inf) = +0); everything else (negative, NaN, inf, denormal) takes the generic
-// models of x86_approx_dev.h.
+// sqrt14(v) = VRCP14(VRSQRT14(v)).  Branch-free for everything the hash actually produces:
+//   v normal, positive, finite -> both table evaluations stay in the normal range (the rsqrt14 result
+//                                 has a biased exponent in [62,190]);
+//   v == +-0                   -> rcp14(+-inf) = +-0;
+//   v negative (not NaN)       -> rsqrt14 gives the QNaN indefinite, rcp14 passes it through.
+// Positive denormals, +inf and NaN inputs (never produced by 8/10-bit content) take the
+// generic models of x86_approx_dev.h behind a rarely-taken branch.
+// out-of-line: executed only for inputs the hash never produces, keeps the hot kernel small
+__device__ __attribute__((noinline)) uint32_t sqrt14_generic(float v, const uint2* tab)
+{
+    return __float_as_uint(x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab));
+}
+
 __device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab)
 {
     const uint32_t x = __float_as_uint(v);
-    if (x - 0x00800000u < 0x7f000000u) {
-        const int E = (int)(x >> 23);
-        uint32_t m = x & 0x7fffffu;
-        const int ue = E - 127, p = ue & 1, half = (ue - p) >> 1;
-        uint2 c = tab[64 + 32 * p + (m >> 18)];
-        uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;
-        uint32_t y = ((uint32_t)(126 - half) << 23) | (code << 7);
-        if ((p | m) == 0) y = (uint32_t)(127 - half) << 23;                 // exact power of four
-        // rcp14 of the (normal) intermediate
-        const int Ey = (int)(y >> 23);
-        m = y & 0x7fffffu;
-        c = tab[m >> 17];
-        code = (c.x - c.y * ((m >> 7) & 1023u)) >> 9;
-        uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code << 7);
-        if (m == 0) z = (uint32_t)(254 - Ey) << 23;
-        return __uint_as_float(z);
+    const bool normal = (x - 0x00800000u) < 0x7f000000u;
+    const uint32_t xs = normal ? x : 0x3f800000u;                          // keep the table indices in range
+    const int E = (int)(xs >> 23);
+    uint32_t m = xs & 0x7fffffu;
+    const int ue = E - 127, p = ue & 1, half = (ue - p) >> 1;
+    uint2 c = tab[64 + 32 * p + (m >> 18)];
+    uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;
+    uint32_t y = ((uint32_t)(126 - half) << 23) | (code << 7);
+    y = ((p | m) == 0) ? ((uint32_t)(127 - half) << 23) : y;               // exact power of four
+    const int Ey = (int)(y >> 23);                                         // rcp14 of the (normal) intermediate
+    m = y & 0x7fffffu;
+    c = tab[m >> 17];
+    code = (c.x - c.y * ((m >> 7) & 1023u)) >> 9;
+    uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code << 7);
+    z = (m == 0) ? ((uint32_t)(254 - Ey) << 23) : z;
+    if (!normal) {
+        if ((x << 1) == 0u) z = x;                                          // +-0
+        else if ((x & 0x80000000u) && (x << 1) <= 0xff000000u) z = 0xffc00000u;   // negative, not NaN
+        else z = sqrt14_generic(v, tab);
     }
-    if (x == 0u) return 0.0f;
-    return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+    return __uint_as_float(z);
 }
 
 template <bool LEGACY>
