@@ -109,9 +109,10 @@ int raisr_hip_process_host(raisr_hip_ctx *ctx,
 int raisr_hip_synchronize(raisr_hip_ctx *ctx);
 
 /* Introspection for tests / profiling ---------------------------------------------------------
- * Copies the last frame's per-pixel hash plane (u16: low byte = first hash or 0xFF, high byte =
- * tail re-hash or 0xFF) and fp32 HR plane of pass `pass_index` to host buffers (either may be NULL). */
-int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint16_t *hash_out, float *hr_out);
+ * Copies the last frame's per-pixel hash plane (u8: bucket 0..215 of the first hash, stale outside the
+ * filtered zone) and HR plane (fp32; binary16 bit patterns in the low half-words in FP16 mode) of pass
+ * `pass_index` to host buffers (either may be NULL). */
+int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash_out, float *hr_out);
 /* Per-kernel HIP-event timing of subsequent process calls: events are recorded around every kernel on
  * the stream it is launched on.  _read() returns the number of distinct kernels and fills, per kernel,
  * its name (64 bytes each), the summed milliseconds and the launch count since _enable(ctx, 1);

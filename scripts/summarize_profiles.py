@@ -54,17 +54,21 @@ if pmc:
     lines += ["| kernel | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
     for k, v in pmc.items():
         lines.append(f"| {k} | " + " | ".join(f"{v.get(c, float('nan')):.4g}" for c in cols) + " |")
-    lines += ["", "Units: SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves; FETCH_SIZE / WRITE_SIZE are KiB as reported",
-              "(MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a wide coalesced stream -> doubled below).", ""]
+    lines += ["", "Units: SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves; FETCH_SIZE / WRITE_SIZE are KiB as reported.",
+              "Calibration (MI355X_MICROARCH.md asks for one per access pattern): the gfx950 half-count of FETCH_SIZE applies to wide",
+              "16-B/lane streams; these kernels load 1-4 B per lane.  Known byte counts: k_resize2x writes exactly one u16 LR plane",
+              "(16 588 800 B = 16 200 KiB == WRITE_SIZE); k_blend must fetch the LR (u16) and HR (f32) planes with an 18/16 x 66/64 tile",
+              "halo = 49.8 MB x 1.16 = 57.7 MB minimum vs FETCH_SIZE 62 980 KiB = 64.5 MB -- i.e. FETCH_SIZE is NOT halved for this",
+              "access pattern, so no x2 correction is applied below.", ""]
     traffic = {}
     for k, v in pmc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            traffic[k] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+            traffic[k] = int((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if traffic:
-        lines += ["## HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
+        lines += ["## HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
         json.dump({"k_hash_hbm_bytes_per_launch": traffic.get("k_hash"), "per_kernel": traffic,
-                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                             "(gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md HBM section)"},
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (FETCH_SIZE + WRITE_SIZE)*1024; "
+                             "no x2 FETCH correction: calibrated on k_resize2x/k_blend known byte counts (narrow per-lane loads), see the summary"},
                   open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -133,9 +133,9 @@ __device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, cons
 // the same for all four pixel classes up to operand order of single additions -- then scaled by NF
 // in fp32 and rounded back (:197-221).
 // ------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256, 4) void k_hash16(const uint16_t* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
-                                                    uint16_t* __restrict__ hash_out)
+template <int R, typename T>
+__global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
+                                                    uint8_t* __restrict__ hash_out)
 {
     constexpr int TH = 4 * R;
     constexpr int LW = 76, LH = TH + 12;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const uint16_t* __restrict__ 
         if (r < P.H - kMargin && c < P.c_final) {
             const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
             const unsigned hA = (unsigned)hash_px16(a, b, d, Q, sTab);
-            hash_out[(size_t)r * P.hash_pitch + c] = (uint16_t)(hA | 0xFF00u);
+            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA;
         }
     }
 }
@@ -239,12 +239,13 @@ __device__ __forceinline__ hf row_ror_h(hf v)
     return h_bits((uint16_t)__builtin_amdgcn_update_dpp(0, bits, CTRL, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(256) void k_filter16(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hash,
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
                                                   PassParams P, Pass16 Q, uint16_t* __restrict__ hr)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;
     __shared__ hf sL[LH * LW];
-    __shared__ uint16_t sH[TH * TW];
+    __shared__ uint8_t sH[TH * TW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
     const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_filter16(const uint16_t* __restrict__ l
     }
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
-        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint16_t)0xFFFFu;
+        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
     }
     __syncthreads();
 
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_filter16(const uint16_t* __restrict__ l
         for (int s = 0; s < 16; s++) {
             const int pcol = 4 * s + g;
             const int c = c0 + pcol;
-            const unsigned hA = sH[prow * TW + pcol] & 0xFFu;
+            const unsigned hA = sH[prow * TW + pcol];
             const int base = prow * LW + pcol;
             const hf center = sL[base + 5 * LW + 5];
             const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void k_filter16(const uint16_t* __restrict__ l
 // 32-wide binary16 body (:303-312), the rest the scalar fp32 tail (:326-352).
 // ------------------------------------------------------------------------------------------------
 template <typename TOut>
-__global__ __launch_bounds__(256) void k_blend16(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hr,
+__global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, const uint16_t* __restrict__ hr,
                                                  PassParams P, Pass16 Q, TOut* __restrict__ out, int out_pitch)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 2, LH = TH + 2;

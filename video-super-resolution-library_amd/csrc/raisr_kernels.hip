@@ -60,13 +60,15 @@ struct GaussW {
 struct PassParams {
     int W, H;                    // plane size of this pass
     int lr_pitch;                // LR plane pitch in u16 elements
-    int hash_pitch;              // hash plane pitch in u16 elements
+    int hash_pitch;              // hash plane pitch in bytes (u8 elements)
     int hr_pitch;                // HR plane pitch in floats
     float lo, hi;                // accept-test / clamp limits as float
     int ilo, ihi;
     int a_begin, a_end;          // columns hashed with the AVX-512 flavour
     int b_begin, b_end;          // columns hashed with the AVX2 flavour (after the AVX-512 one)
     int c_final;                 // first column that is never filtered
+    int ov_begin, ov_end;        // columns hashed twice (AVX-512 flavour, then AVX2): second hash lives in hash2
+    const uint8_t* hash2;        // [H][16] second hash of the overlap columns (column c -> c - ov_begin)
     int pixel_types;             // 4 (ratio 2) or 1
     int randomness;              // 1: BlendingMode Randomness (tail re-hash candidate replaces, never keeps, the first)
     float qangle, qs0, qs1, qc0, qc1;
@@ -273,9 +275,9 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
 // ------------------------------------------------------------------------------------------------
 __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
-template <int R>
-__global__ __launch_bounds__(256, 4) void k_hash(const uint16_t* __restrict__ lr, PassParams P, GaussW gw,
-                                                  uint16_t* __restrict__ hash_out)
+template <int R, typename T>
+__global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassParams P, GaussW gw,
+                                                  uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
 {
     constexpr int TH = 4 * R;
     constexpr int LW = 76, LH = TH + 12;    // LR tile incl. 6-px halo
@@ -359,10 +361,14 @@ __global__ __launch_bounds__(256, 4) void k_hash(const uint16_t* __restrict__ lr
         const f2 ad = (holdAD[j] + curAD[j]) + t1AD[j];      // (Gb+Gc) + (Ga+Gd)
         const float bb = (holdB[j] + curB[j]) + t1B[j];
         if (r < P.H - kMargin && c < P.c_final) {
-            unsigned hA = 0xFFu, hB = 0xFFu;
-            if (c >= P.a_begin && c < P.a_end) hA = (unsigned)hash_px<false>(ad.x, bb, ad.y, P, sTab);
-            if (c >= P.b_begin && c < P.b_end) hB = (unsigned)hash_px<true>(ad.x, bb, ad.y, P, sTab);
-            hash_out[(size_t)r * P.hash_pitch + c] = (uint16_t)(hA | (hB << 8));
+            // first hash: AVX-512 flavour inside its column range, else the AVX2 one (AVX2 mode / no 16-wide chunk)
+            const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+            unsigned h1 = 0xFFu;
+            if (inA) h1 = (unsigned)hash_px<false>(ad.x, bb, ad.y, P, sTab);
+            else if (inB) h1 = (unsigned)hash_px<true>(ad.x, bb, ad.y, P, sTab);
+            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)h1;
+            if (inA && inB)                                         // tail columns re-hashed by the AVX2 routine
+                hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hash_px<true>(ad.x, bb, ad.y, P, sTab);
         }
     }
 }
@@ -391,12 +397,14 @@ __device__ __forceinline__ float tree16(float acc)
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr, const uint16_t* __restrict__ hash,
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
                                                 PassParams P, float* __restrict__ hr)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
     __shared__ float sL[LH * LW];
-    __shared__ uint16_t sH[TH * TW];
+    __shared__ uint8_t sH[TH * TW];         // first hash (0xFF = not filtered)
+    __shared__ uint8_t sH2[TH * TW];        // second hash of the overlap columns (0xFF elsewhere)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
     const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
@@ -410,7 +418,9 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
     }
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
-        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint16_t)0xFFFFu;
+        const bool in = r < P.H - kMargin && c < P.c_final;
+        sH[ty * TW + lane] = in ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
+        sH2[ty * TW + lane] = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : (uint8_t)0xFFu;
     }
     __syncthreads();
 
@@ -443,9 +453,8 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
         bool anyB = false;
 #pragma unroll 4
         for (int s = 0; s < 16; s++) {          // unroll 4 measured best (1: same, 8/16: slower -- code size / occupancy)
-            const unsigned hh = sH[prow * TW + 4 * s + g];
-            const unsigned hA = hh & 0xFFu;
-            anyB |= (hh >> 8) != 0xFFu;
+            const unsigned hA = sH[prow * TW + 4 * s + g];
+            anyB |= sH2[prow * TW + 4 * s + g] != 0xFFu;
             float res = RAISR_LDS_F(ctr, s);
             if (hA != 0xFFu) {
                 const unsigned voff = hA * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
             for (int s = 0; s < 16; s++) {
-                const unsigned hB = sH[prow * TW + 4 * s + g] >> 8;
+                const unsigned hB = sH2[prow * TW + 4 * s + g];
                 if (hB == 0xFFu) continue;
                 const unsigned voff = hB * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
                 float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint16_t* __restrict__ lr,
 // col W-1 keep the unclamped LR value.
 // ------------------------------------------------------------------------------------------------
 template <typename TOut>
-__global__ __launch_bounds__(256) void k_blend(const uint16_t* __restrict__ lr, const float* __restrict__ hr,
+__global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, const float* __restrict__ hr,
                                                PassParams P, TOut* __restrict__ out, int out_pitch)
 {
     // tile 64 x 16 output pixels; wave w owns rows [4w, 4w+4), lane = column.  LR/HR tiles with a
@@ -563,13 +572,13 @@ __global__ __launch_bounds__(256) void k_blend(const uint16_t* __restrict__ lr, 
 // The fp16 pipeline promotes to fp32 for this blend (Raisr.cpp:1224-1230), so one kernel serves both.
 // ------------------------------------------------------------------------------------------------
 template <typename TOut, bool HR16>
-__global__ __launch_bounds__(256) void k_blend_rand(const uint16_t* __restrict__ lr, const void* __restrict__ hr,
+__global__ __launch_bounds__(256) void k_blend_rand(const TOut* __restrict__ lr, const void* __restrict__ hr,
                                                     PassParams P, TOut* __restrict__ out, int out_pitch)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.H) return;
-    const uint16_t lc = lr[(size_t)y * P.lr_pitch + x];
+    const TOut lc = lr[(size_t)y * P.lr_pitch + x];
     const bool zone = y >= kMargin && y < P.H - kMargin && x >= kMargin && x < P.c_final;
     if (!zone) {
         const bool untouched = P.H >= 2 * kMargin + 1 && y == P.H - kMargin - 1 && x >= P.c_final && x < P.W - kMargin;
@@ -684,6 +693,9 @@ void column_plan(int W, int hash_variant, PassParams& P)
     }
     P.c_final = a_any || b_any ? (b_any ? P.b_end : P.a_end) : kMargin;
     if (a_any && b_any && P.a_end > P.b_end) P.c_final = P.a_end;
+    // columns inside both ranges are hashed twice (at most 16 of them: one 16-wide chunk)
+    P.ov_begin = P.ov_end = 0;
+    if (a_any && b_any && P.b_begin < P.a_end) { P.ov_begin = P.b_begin; P.ov_end = P.a_end < P.b_end ? P.a_end : P.b_end; }
 }
 
 }  // namespace
@@ -702,10 +714,11 @@ struct raisr_hip_ctx {
     uint16_t* d_tab16 = nullptr;                // rcpph T, rsqrtph T0, T1
     GaussW16 gauss16{};
     // scratch planes
-    uint16_t* d_lr[2] = {nullptr, nullptr};     // LR plane per pass (u16)
-    uint16_t* d_hash[2] = {nullptr, nullptr};
+    void* d_lr[2] = {nullptr, nullptr};         // LR plane per pass, sample type (u8 for 8-bit content, else u16)
+    uint8_t* d_hash[2] = {nullptr, nullptr};    // first hash per pixel
+    uint8_t* d_hash2[2] = {nullptr, nullptr};   // [H][16] second hash of the tail (overlap) columns
     float* d_hr[2] = {nullptr, nullptr};
-    uint16_t* d_mid = nullptr;                  // two-pass intermediate (u16)
+    void* d_mid = nullptr;                      // two-pass intermediate (sample type), only when the passes differ in size
     int passW[2] = {0, 0}, passH[2] = {0, 0};
     GaussW gauss{};
     // host staging for raisr_hip_process_host
@@ -773,6 +786,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.lo = (float)g.clamp_lo; P.hi = (float)g.clamp_hi;
     P.ilo = g.clamp_lo; P.ihi = g.clamp_hi;
     column_plan(W, g.hash_variant, P);
+    P.hash2 = c->d_hash2[pass];
     P.pixel_types = m.h.pixel_types;
     P.randomness = c->blending == RAISR_HIP_BLEND_RANDOMNESS;
     P.qangle = m.h.qangle;
@@ -795,23 +809,23 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         constexpr int R = 4;        // rows per lane; 8 measured slower (136 VGPRs -> 3 waves/SIMD)
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         timer_begin(c, "k_hash", s, slot);
-        hipLaunchKernelGGL((k_hash<R>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, c->gauss, c->d_hash[pass]);
+        hipLaunchKernelGGL((k_hash<R, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
         timer_end(c, s, slot);
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         timer_begin(c, "k_filter", s, slot);
-        hipLaunchKernelGGL(k_filter, gf, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, c->d_hr[pass]);
+        hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
         timer_end(c, s, slot);
     }
     if (P.randomness) {
         dim3 gb((W + 63) / 64, (H + 3) / 4);
         timer_begin(c, "k_blend_rand", s, slot);
-        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
         timer_end(c, s, slot);
         return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend", s, slot);
-    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
 }
 
@@ -833,22 +847,22 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     if (P.c_final > kMargin && H > 2 * kMargin) {
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         timer_begin(c, "k_hash16", s, slot);
-        hipLaunchKernelGGL((k_hash16<4>), gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
+        hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
         timer_end(c, s, slot);
         timer_begin(c, "k_filter16", s, slot);
-        hipLaunchKernelGGL(k_filter16, gh, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
+        hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
         timer_end(c, s, slot);
     }
     if (P.randomness) {
         dim3 gr((W + 63) / 64, (H + 3) / 4);
         timer_begin(c, "k_blend_rand", s, slot);
-        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
         timer_end(c, s, slot);
         return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend16", s, slot);
-    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const uint16_t*)c->d_lr[pass], (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
+    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
 }
 
@@ -857,8 +871,9 @@ void free_scratch(raisr_hip_ctx* c)
     for (int i = 0; i < 2; i++) {
         if (c->d_lr[i]) (void)hipFree(c->d_lr[i]);
         if (c->d_hash[i]) (void)hipFree(c->d_hash[i]);
+        if (c->d_hash2[i]) (void)hipFree(c->d_hash2[i]);
         if (c->d_hr[i]) (void)hipFree(c->d_hr[i]);
-        c->d_lr[i] = nullptr; c->d_hash[i] = nullptr; c->d_hr[i] = nullptr;
+        c->d_lr[i] = nullptr; c->d_hash[i] = nullptr; c->d_hash2[i] = nullptr; c->d_hr[i] = nullptr;
     }
     if (c->d_mid) (void)hipFree(c->d_mid);
     c->d_mid = nullptr;
@@ -1036,20 +1051,25 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     c->passW[0] = mode2 ? cfg->in_width : cfg->out_width;
     c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
     c->passW[1] = cfg->out_width; c->passH[1] = cfg->out_height;
+    const size_t bps = cfg->bits == 8 ? 1 : 2;
     for (int p = 0; p < cfg->passes; p++) {
         const size_t n = (size_t)c->passW[p] * c->passH[p];
-        if (hipMalloc((void**)&c->d_lr[p], n * sizeof(uint16_t)) != hipSuccess ||
-            hipMalloc((void**)&c->d_hash[p], n * sizeof(uint16_t)) != hipSuccess ||
+        if (hipMalloc((void**)&c->d_lr[p], n * bps) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash[p], n) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash2[p], (size_t)c->passH[p] * 16) != hipSuccess ||
             hipMalloc((void**)&c->d_hr[p], n * sizeof(float)) != hipSuccess) {
             free_scratch(c);
             return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
         }
     }
     if (cfg->passes == 2) {
-        const size_t n = (size_t)c->passW[0] * c->passH[0];
-        if (hipMalloc((void**)&c->d_mid, n * sizeof(uint16_t)) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
-        HIP_TRY(hipMemset(c->d_mid, 0, n * sizeof(uint16_t)));   // pixels the Randomness pass never writes stay 0
-        HIP_TRY(hipMemset(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * sizeof(uint16_t)));
+        // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
+        HIP_TRY(hipMemset(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * bps));
+        if (c->passW[0] != c->passW[1] || c->passH[0] != c->passH[1]) {
+            const size_t n = (size_t)c->passW[0] * c->passH[0];
+            if (hipMalloc((void**)&c->d_mid, n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
+            HIP_TRY(hipMemset(c->d_mid, 0, n * bps));
+        }
     }
     c->blending = cfg->blending;
     c->configured = true;
@@ -1076,30 +1096,29 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
     if (in_pitch % bps || out_pitch % bps) return fail(RAISR_HIP_EINVAL, "pitch not a multiple of the sample size");
     const int ipe = (int)(in_pitch / bps), ope = (int)(out_pitch / bps);
 
-    // pass-1 LR: cheap upscale of the input (or an identity widen when pass 1 runs at input size)
-    {
-        ResizeParams R = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
-        if (bps == 1) launch_resize<uint8_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
-        else launch_resize<uint16_t, uint16_t>(c, s, d_in, c->d_lr[0], R, "k_resize");
-    }
+    // Every plane of the pipeline (LR, two-pass intermediate, output) has the sample type of the content:
+    // u8 for 8-bit, u16 above.  pass-1 LR = cheap upscale of the input (a copy when pass 1 runs at input size).
     const bool fp16 = g.hash_variant == RAISR_HIP_HASH_FP16;
-    if (g.passes == 1) {
-        if (fp16) run_pass16<uint8_t>(c, s, 0, d_out, ope);
-        else if (bps == 1) run_pass<uint8_t>(c, s, 0, d_out, ope); else run_pass<uint16_t>(c, s, 0, d_out, ope);
-    } else {
-        // pass 1 writes the 8/10-bit intermediate (Raisr.cpp:927-934).  When both passes run at output size
-        // (mode 1) the intermediate IS pass 2's LR plane; in mode 2 it is upscaled now (Raisr.cpp:945-975).
-        const bool same = c->passW[0] == c->passW[1] && c->passH[0] == c->passH[1];
-        uint16_t* mid = same ? c->d_lr[1] : c->d_mid;
-        if (fp16) run_pass16<uint16_t>(c, s, 0, mid, c->passW[0]);
-        else run_pass<uint16_t>(c, s, 0, mid, c->passW[0]);
-        if (!same) {
-            ResizeParams R = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
-            launch_resize<uint16_t, uint16_t>(c, s, c->d_mid, c->d_lr[1], R, "k_resize");
+    const bool same = g.passes == 2 && c->passW[0] == c->passW[1] && c->passH[0] == c->passH[1];
+    auto job = [&](auto tag) {
+        using T = decltype(tag);
+        ResizeParams R0 = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
+        launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
+        if (g.passes == 1) {
+            if (fp16) run_pass16<T>(c, s, 0, d_out, ope); else run_pass<T>(c, s, 0, d_out, ope);
+            return;
         }
-        if (fp16) run_pass16<uint8_t>(c, s, 1, d_out, ope);
-        else if (bps == 1) run_pass<uint8_t>(c, s, 1, d_out, ope); else run_pass<uint16_t>(c, s, 1, d_out, ope);
-    }
+        // pass 1 writes the integer intermediate (Raisr.cpp:927-934).  When both passes run at output size
+        // (mode 1) the intermediate IS pass 2's LR plane; in mode 2 it is upscaled now (Raisr.cpp:945-975).
+        void* mid = same ? c->d_lr[1] : c->d_mid;
+        if (fp16) run_pass16<T>(c, s, 0, mid, c->passW[0]); else run_pass<T>(c, s, 0, mid, c->passW[0]);
+        if (!same) {
+            ResizeParams R1 = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
+            launch_resize<T, T>(c, s, c->d_mid, c->d_lr[1], R1, "k_resize");
+        }
+        if (fp16) run_pass16<T>(c, s, 1, d_out, ope); else run_pass<T>(c, s, 1, d_out, ope);
+    };
+    if (bps == 1) job(uint8_t{}); else job(uint16_t{});
     HIP_TRY(hipGetLastError());
     return RAISR_HIP_OK;
 }
@@ -1175,14 +1194,14 @@ int raisr_hip_process_host(raisr_hip_ctx* c,
     return RAISR_HIP_OK;
 }
 
-int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint16_t* hash_out, float* hr_out)
+int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint8_t* hash_out, float* hr_out)
 {
     if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
     if (!c->configured || !c->d_hash[pass_index]) return fail(RAISR_HIP_ESTATE, "pass not configured");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)c->passW[pass_index] * c->passH[pass_index];
-    if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n, hipMemcpyDeviceToHost));
     if (hr_out) HIP_TRY(hipMemcpy(hr_out, c->d_hr[pass_index], n * sizeof(float), hipMemcpyDeviceToHost));
     return RAISR_HIP_OK;
 }

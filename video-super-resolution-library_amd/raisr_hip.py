@@ -281,7 +281,7 @@ class RaisrDevice:
         mode2 = self.cfg.passes == 2 and self.cfg.two_pass_mode == 2
         w = self.cfg.in_width if (pass_index == 0 and mode2) else self.cfg.out_width
         h = self.cfg.in_height if (pass_index == 0 and mode2) else self.cfg.out_height
-        hs = np.zeros((h, w), np.uint16); hr = np.zeros((h, w), np.float32)
+        hs = np.zeros((h, w), np.uint8); hr = np.zeros((h, w), np.float32)
         _check(lib().raisr_hip_debug_read_stage(self._h, pass_index, hs.ctypes.data, hr.ctypes.data), "debug_read_stage")
         return hs, hr
 
