@@ -173,6 +173,60 @@ static void gtwg_pixel(const float *L, int W, int r, int c, int odd, const float
     *a = tree11(A, odd); *b = tree11(B, odd); *d = tree11(D, odd);
 }
 
+/* Same arithmetic as gtwg_pixel() for a run of pixels x in [x0, x1) of row r, with the loops ordered
+ * (patch column, patch row, pixel) so that the innermost loop is a unit-stride sweep the compiler
+ * vectorises (speed of the CPU baseline only; every lane performs exactly gtwg_pixel's operations in
+ * gtwg_pixel's order).  tests/test_oracle_facts.py checks the two forms give identical bits. */
+#define GT_BLK 256
+static void gtwg_row(const float *L, int W, int r, int x0, int x1, const float w[PATCH][PATCH],
+                     float *a, float *b, float *d)
+{
+    float SA[PATCH][GT_BLK], SB[PATCH][GT_BLK], SD[PATCH][GT_BLK];
+    for (int xb = x0; xb < x1; xb += GT_BLK) {
+        const int n = (x1 - xb) < GT_BLK ? (x1 - xb) : GT_BLK;
+        for (int k = 0; k < PATCH; k++) {
+            float *restrict sa = SA[k], *restrict sb = SB[k], *restrict sd = SD[k];
+            for (int x = 0; x < n; x++) { sa[x] = 0.0f; sb[x] = 0.0f; sd[x] = 0.0f; }
+            for (int i = 0; i < PATCH; i++) {
+                const float wv = w[i][k];
+                const float *restrict up = L + (size_t)(r - PM + i - 1) * W + (xb - PM + k);
+                const float *restrict mid = L + (size_t)(r - PM + i) * W + (xb - PM + k);
+                const float *restrict dn = L + (size_t)(r - PM + i + 1) * W + (xb - PM + k);
+                for (int x = 0; x < n; x++) {
+                    const float gx = dn[x] - up[x];
+                    const float gy = mid[x + 1] - mid[x - 1];
+                    const float p = gx * wv;
+                    sa[x] = fmaf(p, gx, sa[x]);
+                    sb[x] = fmaf(p, gy, sb[x]);
+                    const float q = gy * wv;
+                    sd[x] = fmaf(q, gy, sd[x]);
+                }
+            }
+        }
+        for (int x = 0; x < n; x++) {
+            float S[PATCH];
+            const int odd = (xb + x) & 1;      /* chunk starts are even, so pair parity == column parity */
+            for (int k = 0; k < PATCH; k++) S[k] = SA[k][x];
+            a[xb + x] = tree11(S, odd);
+            for (int k = 0; k < PATCH; k++) S[k] = SB[k][x];
+            b[xb + x] = tree11(S, odd);
+            for (int k = 0; k < PATCH; k++) S[k] = SD[k][x];
+            d[xb + x] = tree11(S, odd);
+        }
+    }
+}
+
+/* exported for the equivalence test */
+void ora_gtwg_both(const float *L, int W, int r, int c, int bits, float out6[6])
+{
+    float w[PATCH][PATCH];
+    ora_gaussian_weights(bits, w);
+    gtwg_pixel(L, W, r, c, c & 1, w, &out6[0], &out6[1], &out6[2]);
+    float a[GT_BLK + 16], b[GT_BLK + 16], d[GT_BLK + 16];
+    gtwg_row(L, W, r, c, c + 1, w, a - c + 0, b - c + 0, d - c + 0);
+    out6[3] = a[0]; out6[4] = b[0]; out6[5] = d[0];
+}
+
 /* ------------------------------------------------------------------------------------------
  * A.4 hash.  x86 cvtps_epi32 semantics: NaN / out of range -> INT_MIN.
  * ------------------------------------------------------------------------------------------ */
@@ -236,18 +290,15 @@ static int hash_pixel(float a, float b, float d, const ora_pass_t *P, int avx2_v
  * ------------------------------------------------------------------------------------------ */
 static float dot_patch(const float *L, int W, int r, int c, const float *f)
 {
-    float acc[16];
-    for (int l = 0; l < 16; l++) {
-        int k = l;
-        acc[l] = L[(size_t)(r - PM + k / PATCH) * W + (c - PM + k % PATCH)] * f[k];
-    }
+    /* pixbuf[128] / filter row padded to 128 with +0 (Raisr.cpp:1056, :329-331) */
+    float pb[128], fb[128], acc[16];
+    for (int i = 0; i < PATCH; i++)
+        for (int j = 0; j < PATCH; j++) pb[i * PATCH + j] = L[(size_t)(r - PM + i) * W + (c - PM + j)];
+    for (int k = 0; k < TAPS; k++) fb[k] = f[k];
+    for (int k = TAPS; k < 128; k++) { pb[k] = 0.0f; fb[k] = 0.0f; }
+    for (int l = 0; l < 16; l++) acc[l] = pb[l] * fb[l];
     for (int ch = 1; ch < 8; ch++)
-        for (int l = 0; l < 16; l++) {
-            int k = 16 * ch + l;
-            float pv = 0.0f, fv = 0.0f;                    /* padding 121..127 is +0 (Raisr.cpp:1056, :329-331) */
-            if (k < TAPS) { pv = L[(size_t)(r - PM + k / PATCH) * W + (c - PM + k % PATCH)]; fv = f[k]; }
-            acc[l] = fmaf(pv, fv, acc[l]);
-        }
+        for (int l = 0; l < 16; l++) acc[l] = fmaf(pb[16 * ch + l], fb[16 * ch + l], acc[l]);
     float t[8], u[4];
     for (int i = 0; i < 8; i++) t[i] = acc[i] + acc[i + 8];
     for (int i = 0; i < 4; i++) u[i] = t[i] + t[i + 4];
@@ -295,6 +346,8 @@ void ora_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t *o
 
     #pragma omp parallel for schedule(dynamic, 2)
     for (int r = LM; r < H - LM; r++) {                            /* Raisr.cpp:1036-1058 */
+        float *ga = (float *)malloc(sizeof(float) * 3 * (size_t)W), *gb = ga + W, *gd = gb + W;
+        if (W > 2 * LM) gtwg_row(L, W, r, LM, W - LM, wg, ga, gb, gd);
         int unroll = P->asm_type == ORA_ASM_AVX512 ? 16 : 8;       /* unrollSizePatchBased, :1481-1528 */
         int loopItr = unroll;
         int c = LM;
@@ -303,8 +356,8 @@ void ora_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t *o
             for (int pix = 0; pix < loopItr; pix++) {
                 int cc = c + pix;
                 int odd = pix & 1;                                 /* pair position inside computeGTWG call */
-                float a, b, d;
-                gtwg_pixel(L, W, r, cc, odd, wg, &a, &b, &d);
+                (void)odd;
+                const float a = ga[cc], b = gb[cc], d = gd[cc];   /* == gtwg_pixel(L, W, r, cc, odd, ...) */
                 int h = hash_pixel(a, b, d, P, avx2_hash);
                 int t = 0;
                 if (P->pixel_types == 4) t = ((r - PM) % 2) * 2 + ((cc - PM) % 2);   /* :1068-1096 */
@@ -330,6 +383,7 @@ void ora_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t *o
             if (loopItr > 8 && c + 2 * unroll > W - LM) loopItr = 8;   /* :1246-1249 */
             c += loopItr;
         }
+        free(ga);
     }
 
     if (!randomness) {

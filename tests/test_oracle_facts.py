@@ -103,3 +103,19 @@ def test_regression_fixtures():
             out = oracle_y(fr, (cid, fold, (rn, rd), bits, passes, mode, asm, full))
             got[f"{cid}/{nm}"] = hashlib.sha256(out.tobytes()).hexdigest()
     assert got == want
+
+
+def test_vectorised_gtwg_row_equals_the_scalar_form():
+    """The CPU-baseline-friendly loop order (gtwg_row) must give the bits of the line-by-line
+    restatement (gtwg_pixel) for every pixel parity and bit depth."""
+    import oracle_py as O
+    L = O.lib()
+    L.ora_gtwg_both.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(11)
+    for bits in (8, 10):
+        plane = rng.integers(0, 1 << bits, (40, 64)).astype(np.float32)
+        out = np.zeros(6, np.float32)
+        for r in (6, 17, 33):
+            for c in (6, 7, 20, 41, 57):
+                L.ora_gtwg_both(plane.ctypes.data, 64, r, c, bits, out.ctypes.data)
+                assert np.array_equal(out[:3].view(np.uint32), out[3:].view(np.uint32)), (bits, r, c, out)
