@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=24)
     ap.add_argument("--lanes", type=int, default=3, help="frames in flight per GPU (one context+stream each); 3 measured best")
-    ap.add_argument("--passes", type=int, default=1)
+    ap.add_argument("--passes", type=int, default=0, help="override the config's pass count (1 or 2)")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration; the bench line is C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=30)
@@ -40,10 +41,36 @@ def parse():
     return ap.parse_args()
 
 
-IN_W, IN_H, OUT_W, OUT_H = 1920, 1080, 3840, 2160
-FOLDER = os.path.join(ROOT, "filters_2x", "filters_highres")
-ALGO_BYTES_PER_FRAME = IN_W * IN_H + OUT_W * OUT_H          # 10 368 000 B
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
+
+# BASELINE.json configs.  The bench line is C2 (configs[1]); the others are selectable for
+# profiling: (in_w, in_h, out_w, out_h, folder, bits, passes, mode, hash variant, description)
+CONFIGS = {
+    "C1": (960, 540, 1920, 1080, "filters_2x/filters_lowres", 8, 1, 1, 1, "540p->1080p 2x, filters_lowres, 1-pass, 8-bit, AVX2-exact"),
+    "C2": (1920, 1080, 3840, 2160, "filters_2x/filters_highres", 8, 1, 1, 2, "1080p->4K 2x, filters_2x/filters_highres, 1-pass, 8-bit, AVX512-exact"),
+    "C3": (1920, 1080, 3840, 2160, "filters_2x/filters_highres", 8, 2, 1, 2, "1080p->4K 2x, filters_2x/filters_highres, 2-pass, 8-bit, AVX512-exact"),
+    "C4": (1280, 720, 1920, 1080, "filters_1.5x/filters_denoise", 8, 2, 2, 5, "720p->1080p 1.5x, filters_denoise, 2-pass mode 2, 8-bit, AVX512FP16-exact"),
+    "C5": (3840, 2160, 7680, 4320, "filters_2x/filters_highres", 10, 1, 1, 2, "4K->8K 2x, filters_highres, 1-pass, 10-bit, AVX512-exact"),
+}
+IN_W = IN_H = OUT_W = OUT_H = 0
+FOLDER = ""
+ALGO_BYTES_PER_FRAME = 0
+CFG = None
+
+
+def select_config(name, passes_override=None):
+    """Sets the module-level workload.  Algorithmic bytes: Y in + Y out per frame, plus the
+    intermediate write + read for two passes (C2: 10 368 000 B)."""
+    global IN_W, IN_H, OUT_W, OUT_H, FOLDER, ALGO_BYTES_PER_FRAME, CFG
+    iw, ih, ow, oh, folder, bits, passes, mode, asm, desc = CONFIGS[name]
+    if passes_override:
+        passes = passes_override
+    IN_W, IN_H, OUT_W, OUT_H = iw, ih, ow, oh
+    FOLDER = os.path.join(ROOT, *folder.split("/"))
+    bps = 1 if bits == 8 else 2
+    mid = (iw * ih if mode == 2 else ow * oh) * bps
+    ALGO_BYTES_PER_FRAME = (iw * ih + ow * oh) * bps + (2 * mid if passes == 2 else 0)
+    CFG = dict(name=name, bits=bits, passes=passes, mode=mode, asm=asm, desc=desc, pixel_types=4 if ow == 2 * iw else 1)
 
 
 def cpu_baseline(sample_frames):
@@ -60,20 +87,29 @@ def cpu_baseline(sample_frames):
         pass
     os.environ["OMP_NUM_THREADS"] = str(cores)
     O.lib()
-    p1 = O.make_pass(O.Model(FOLDER, 8, 1), 8, False, O.ASM_AVX512)
-    frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + i) for i in range(sample_frames)]
-    O.process_y(frames[0][:128, :256], 512, 256, p1)         # warm the thread pool / page in
+    bits, passes, mode, asm = CFG["bits"], CFG["passes"], CFG["mode"], CFG["asm"]
+    if asm == 5:
+        p1 = O.make_pass16(FOLDER, bits, 1)
+        p2 = O.make_pass16(FOLDER, bits, 2) if passes == 2 else None
+        run = lambda f: O.process_y16(f, OUT_W, OUT_H, p1, p2, passes, mode)
+    else:
+        p1 = O.make_pass(O.Model(FOLDER, bits, 1), bits, False, asm)
+        p2 = O.make_pass(O.Model(FOLDER, bits, 2), bits, False, asm) if passes == 2 else None
+        run = lambda f: O.process_y(f, OUT_W, OUT_H, p1, p2, passes, mode)
+    frames = [synth.natural_y(IN_W, IN_H, bits, seed=12345 + i) for i in range(min(sample_frames, 4))]
+    run(frames[0])                                           # warm the thread pool / page in
     t0 = time.perf_counter()
-    for f in frames:
-        O.process_y(f, OUT_W, OUT_H, p1)
+    for i in range(sample_frames):
+        run(frames[i % len(frames)])
     dt = time.perf_counter() - t0
     return {"value": round(OUT_W * OUT_H * sample_frames / dt / 1e6, 3), "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_frames} synthetic 1080p->4K frames, 1-pass; scalar (non-SIMD) C oracle, OpenMP row bands, "
-                      f"threads = cgroup CPU quota, {dt:.2f}s"}
+            "sample": f"{sample_frames} synthetic frames of the same workload ({CFG['name']}); C oracle (gcc -O3 -mavx2 auto-vectorised, "
+                      f"strict IEEE), OpenMP row bands, threads = cgroup CPU quota, {dt:.2f}s"}
 
 
 def main():
     args = parse()
+    select_config(args.config, args.passes or None)
     import torch
     import torch.distributed as dist
     import raisr_hip as R
@@ -91,14 +127,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- model: rank 0 reads the files and packs the device blob; RCCL broadcast to the others ----
-    passes = args.passes
+    passes = CFG["passes"]
+    bits = CFG["bits"]
     blobs = []
     for p in range(passes):
         host_blob = None
         if rank == 0:
-            bank, qstr, qcoh, qa = R.read_model_folder(FOLDER, 8, p + 1)
+            bank, qstr, qcoh, qa = R.read_model_folder(FOLDER, bits, p + 1)
             host_blob = R.pack_model_blob(bank, qstr, qcoh, qa)
-        nbytes = R.lib().raisr_hip_model_blob_bytes(216, 4)
+        nbytes = R.lib().raisr_hip_model_blob_bytes(216, CFG["pixel_types"])
         blobs.append(sharding.broadcast_model_blob(host_blob, nbytes, dev, dist if world > 1 else None))
     torch.cuda.synchronize()
 
@@ -107,7 +144,7 @@ def main():
         d = R.RaisrDevice(local_rank)
         for p in range(passes):
             d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
-        d.configure(IN_W, IN_H, OUT_W, OUT_H, bits=8, passes=passes, mode=1, hash_variant=R.HASH_AVX512)
+        d.configure(IN_W, IN_H, OUT_W, OUT_H, bits=bits, passes=passes, mode=CFG["mode"], hash_variant=CFG["asm"])
         lanes.append(d)
 
     # ---- synthetic input, resident in HBM before the timed region ----
@@ -116,19 +153,20 @@ def main():
     # each rank owns its own frames of the (virtual) stream: frame index = rank + world * i
     mine = sharding.frames_for_rank(uniq * world, rank, world)
     if args.frame_kind == "natural":
-        host_frames = [synth.natural_y(IN_W, IN_H, 8, seed=12345 + i) for i in mine]
+        host_frames = [synth.natural_y(IN_W, IN_H, bits, seed=12345 + i) for i in mine]
     elif args.frame_kind == "random":
-        host_frames = [synth.random_y(IN_W, IN_H, 8, seed=777 + i) for i in mine]
+        host_frames = [synth.random_y(IN_W, IN_H, bits, seed=777 + i) for i in mine]
     else:
-        host_frames = [synth.FRAME_KINDS[args.frame_kind](IN_W, IN_H, 8) for _ in mine]
+        host_frames = [synth.FRAME_KINDS[args.frame_kind](IN_W, IN_H, bits) for _ in mine]
     d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
-    d_out = [torch.empty((OUT_H, OUT_W), dtype=torch.uint8, device=dev) for _ in range(args.lanes)]
+    bps = 1 if bits == 8 else 2
+    d_out = [torch.empty((OUT_H, OUT_W), dtype=torch.uint8 if bps == 1 else torch.uint16, device=dev) for _ in range(args.lanes)]
     torch.cuda.synchronize()
 
     def step():
         for f in range(nf):
             ln = f % args.lanes
-            lanes[ln].process_y(d_in[f % uniq].data_ptr(), IN_W, d_out[ln].data_ptr(), OUT_W)
+            lanes[ln].process_y(d_in[f % uniq].data_ptr(), IN_W * bps, d_out[ln].data_ptr(), OUT_W * bps)
 
     def fence():
         torch.cuda.synchronize()
@@ -165,19 +203,22 @@ def main():
     if rank == 0:
         roofline = None
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
-        if "k_hash" in kern and kern["k_hash"]["count"]:
-            avg_s = kern["k_hash"]["total_ms"] / kern["k_hash"]["count"] * 1e-3
-            achieved = ALGO_BYTES_PER_FRAME / avg_s / 1e9
+        dom = "k_hash16" if CFG["asm"] == 5 else "k_hash"
+        if dom in kern and kern[dom]["count"]:
+            # with two passes the kernel runs twice per frame: one launch still processes one frame-pass
+            avg_s = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3
+            algo_per_launch = ALGO_BYTES_PER_FRAME / passes
+            achieved = algo_per_launch / avg_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and CFG["name"] == "C2":
                 try:
                     traffic = json.load(open(tpath)).get("k_hash_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_hash", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                        "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME,
+                        "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": int(algo_per_launch),
                         "note": "path is fp32-VALU bound (~1 kFLOP per output pixel vs 1.25 compulsory bytes); "
                                 "HBM fraction is reported as required, VALU utilisation is the binding figure (DESIGN.md)"}
         cpu = None
@@ -187,12 +228,11 @@ def main():
             except Exception as e:  # the baseline is reported data, never a reason to lose the GPU line
                 cpu = {"value": None, "unit": "MP/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         line = {
-            "metric": "megapixels/sec (Y-plane) 1080p->4K 2x RAISR",
+            "metric": "megapixels/sec (Y-plane) 1080p->4K 2x RAISR" if CFG["name"] in ("C2", "C3") else f"megapixels/sec (Y-plane) {CFG['name']}",
             "value": round(mp_s, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"1080p->4K 2x, filters_2x/filters_highres, {passes}-pass, 8-bit, CT blend, "
-                                   "AVX512-exact numerics, frames resident in HBM",
+            "config": {"workload": f"{CFG['name']}: {CFG['desc']}, CT blend, frames resident in HBM" + (f" [passes={passes}]" if args.passes else ""),
                        "frame_kind": args.frame_kind,
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "parallelism": f"frame-shard x{world}"},
