@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
     __shared__ uint16_t sTab[3072];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = kMargin + blockIdx.x * 64, r0 = kMargin + blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
     for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 6 + ty, 0), P.H - 1);
@@ -248,7 +250,9 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
     __shared__ uint8_t sH[TH * TW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
-    const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
@@ -318,7 +322,9 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
     __shared__ float sL[LH * LW];
     __shared__ float sHh[LH * LW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = bx * TW, r0 = by * TH;
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
         const bool rowz = gy >= kMargin && gy < P.H - kMargin;

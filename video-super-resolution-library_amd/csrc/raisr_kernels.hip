@@ -77,6 +77,21 @@ struct PassParams {
     const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
 };
 
+// XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
+// each XCD has a private 4 MiB L2, so with the plain (blockIdx.x, blockIdx.y) order the eight tiles around
+// any tile live in eight different L2s and every halo row/column is fetched from HBM again.  Remap the
+// dispatch index so that each XCD walks one contiguous row-major strip of tiles: neighbouring tiles then
+// share an L2 and the halo re-reads hit it.  Pure performance: any placement gives the same result.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by)
+{
+    const unsigned gx = gridDim.x, n = gridDim.x * gridDim.y;
+    const unsigned b = blockIdx.y * gx + blockIdx.x;
+    const unsigned n8 = n & ~7u;
+    const unsigned t = b < n8 ? (b & 7u) * (n8 >> 3) + (b >> 3) : b;
+    by = (int)(t / gx);
+    bx = (int)(t - (unsigned)by * gx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_resize: centre-aligned bilinear with replicate border in exact integer arithmetic.
 // dst(y,x): n = (2d+1)*S - D, den = 2D per axis (reduced by gcd on the host: Sx,Dx,Sy,Dy).
@@ -287,7 +302,9 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     __shared__ uint2 sTab[128];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = kMargin + blockIdx.x * 64, r0 = kMargin + blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
 
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
     for (int ty = w; ty < LH; ty += 4) {
@@ -407,7 +424,9 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
     __shared__ uint8_t sH2[TH * TW];        // second hash of the overlap columns (0xFF elsewhere)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
-    const int c0 = kMargin + blockIdx.x * TW, r0 = kMargin + blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
@@ -504,7 +523,9 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     __shared__ float sL[LH * LW];
     __shared__ float sH[LH * LW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = bx * TW, r0 = by * TH;
     for (int ty = w; ty < LH; ty += 4) {
         const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
         const bool rowz = gy >= kMargin && gy < P.H - kMargin;
