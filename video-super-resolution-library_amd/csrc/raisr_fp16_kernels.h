@@ -149,20 +149,18 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
     for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1);
-        for (int tx = lane; tx < LW; tx += 64) {
-            const int gx = min(max(c0 - 6 + tx, 0), P.W - 1);
-            sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];     // exact for 8-bit content
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {     // linear sweep: every lane busy
+        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1), gx = min(max(c0 - 6 + tx, 0), P.W - 1);
+        sL[idx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];                    // exact for 8-bit content
     }
     __syncthreads();
-    for (int ty = w; ty < GH; ty += 4)
-        for (int tx = lane; tx < GW_; tx += 64) {
-            const hf gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
-            const hf gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
-            sG[ty * GW_ + tx] = (hf2){gxv, gyv};
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
+        const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
+        const hf gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+        const hf gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+        sG[idx] = (hf2){gxv, gyv};
+    }
     __syncthreads();
 
     hf2 curAD[R], holdAD[R], t1AD[R];
@@ -254,12 +252,10 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
-        for (int tx = lane; tx < TW + 10; tx += 64) {
-            const int gx = min(max(c0 - 5 + tx, 0), P.W - 1);
-            sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * (TW + 10)); idx += 256) {   // linear sweep: every lane busy
+        const int ty = (int)(idx / (TW + 10)), tx = (int)(idx - (unsigned)ty * (TW + 10));
+        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1), gx = min(max(c0 - 5 + tx, 0), P.W - 1);
+        sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];
     }
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
@@ -325,17 +321,14 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
-        const bool rowz = gy >= kMargin && gy < P.H - kMargin;
-        for (int tx = lane; tx < LW; tx += 64) {
-            const int gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-            const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
-            float Hv = L;
-            if (rowz && gx >= kMargin && gx < P.c_final) Hv = (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]);
-            sL[ty * LW + tx] = L;                 // binary16 values widened exactly
-            sHh[ty * LW + tx] = Hv;
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {      // linear sweep: every lane busy
+        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+        const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
+        float Hv = L;                                                               // HR := LR outside the filtered zone
+        if (gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final) Hv = (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]);
+        sL[idx] = L;
+        sHh[idx] = Hv;
     }
     __syncthreads();
     const int x = c0 + lane;

@@ -307,21 +307,19 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
 
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1);
-        for (int tx = lane; tx < LW; tx += 64) {
-            const int gx = min(max(c0 - 6 + tx, 0), P.W - 1);
-            sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {     // linear sweep: every lane busy
+        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1), gx = min(max(c0 - 6 + tx, 0), P.W - 1);
+        sL[idx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
     }
     __syncthreads();
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
-    for (int ty = w; ty < GH; ty += 4)
-        for (int tx = lane; tx < GW_; tx += 64) {
-            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
-            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
-            sG[ty * GW_ + tx] = (f2){gxv, gyv};
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
+        const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
+        const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];            // GetGx: row below - row above
+        const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];          // GetGy: right - left
+        sG[idx] = (f2){gxv, gyv};
+    }
     __syncthreads();
 
     f2 curAD[R], holdAD[R], t1AD[R];
@@ -428,12 +426,10 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1);
-        for (int tx = lane; tx < TW + 10; tx += 64) {
-            const int gx = min(max(c0 - 5 + tx, 0), P.W - 1);
-            sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * (TW + 10)); idx += 256) {   // linear sweep: every lane busy
+        const int ty = (int)(idx / (TW + 10)), tx = (int)(idx - (unsigned)ty * (TW + 10));
+        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1), gx = min(max(c0 - 5 + tx, 0), P.W - 1);
+        sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
     }
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
@@ -526,17 +522,14 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    for (int ty = w; ty < LH; ty += 4) {
-        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1);
-        const bool rowz = gy >= kMargin && gy < P.H - kMargin;
-        for (int tx = lane; tx < LW; tx += 64) {
-            const int gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-            const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
-            float Hv = L;
-            if (rowz && gx >= kMargin && gx < P.c_final) Hv = hr[(size_t)gy * P.hr_pitch + gx];
-            sL[ty * LW + tx] = L;
-            sH[ty * LW + tx] = Hv;
-        }
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {      // linear sweep: every lane busy
+        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+        const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
+        float Hv = L;                                                               // HR := LR outside the filtered zone
+        if (gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final) Hv = hr[(size_t)gy * P.hr_pitch + gx];
+        sL[idx] = L;
+        sH[idx] = Hv;
     }
     __syncthreads();
     const int x = c0 + lane;
@@ -667,10 +660,11 @@ struct ModelDev {
 
 struct KernelTimer {
     struct Rec { int id; hipEvent_t a, b; };
-    std::vector<Rec> recs;
+    std::vector<Rec> recs;                 // recs[i] uses pool[2i], pool[2i+1]
+    std::vector<hipEvent_t> pool;          // created once at enable time, outside any timed region
     std::vector<std::string> names;
     bool enabled = false;
-    size_t cap = 8192;
+    size_t cap = 4096;                     // launches recorded per enable; later launches run untimed
 };
 
 int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -758,8 +752,9 @@ void timer_begin(raisr_hip_ctx* c, const char* name, hipStream_t s, int& slot)
     int id = -1;
     for (size_t i = 0; i < T.names.size(); i++) if (T.names[i] == name) { id = (int)i; break; }
     if (id < 0) { T.names.push_back(name); id = (int)T.names.size() - 1; }
-    KernelTimer::Rec r{id, nullptr, nullptr};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    const size_t i = T.recs.size();
+    if (2 * i + 1 >= T.pool.size()) return;
+    KernelTimer::Rec r{id, T.pool[2 * i], T.pool[2 * i + 1]};
     (void)hipEventRecord(r.a, s);
     T.recs.push_back(r);
     slot = (int)T.recs.size() - 1;
@@ -956,7 +951,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto& r : c->timer.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : c->timer.pool) if (e) (void)hipEventDestroy(e);
     free_scratch(c);
     for (int i = 0; i < 2; i++) if (c->model[i].blob) hipFree(c->model[i].blob);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
@@ -1233,8 +1228,12 @@ int raisr_hip_kernel_timing_enable(raisr_hip_ctx* c, int on)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
     KernelTimer& T = c->timer;
-    for (auto& r : T.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     T.recs.clear(); T.names.clear();
+    if (on && T.pool.empty()) {
+        HIP_TRY(hipSetDevice(c->device));
+        T.pool.resize(2 * T.cap);
+        for (auto& e : T.pool) HIP_TRY(hipEventCreate(&e));
+    }
     T.enabled = on != 0;
     return RAISR_HIP_OK;
 }
