@@ -822,7 +822,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     PassParams P = make_pass(c, pass, W, H);
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
-        constexpr int R = 4;        // rows per lane; 8 measured slower (136 VGPRs -> 3 waves/SIMD)
+        constexpr int R = 4;        // rows per lane: 3..6 measure the same within noise, 8 is slower (occupancy)
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         timer_begin(c, "k_hash", s, slot);
         hipLaunchKernelGGL((k_hash<R, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
