@@ -23,6 +23,9 @@ CASES = [
     ("2x_highres_8b_full", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, True),
     ("1.5x_highres_8b_1p", "filters_1.5x/filters_highres", (3, 2), 8, 1, 1, 2, False),
     ("1.5x_denoise_8b_2p_m2", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 2, False),
+    ("2x_denoise_10b_2p_m2", "filters_2x/filters_denoise", (2, 1), 10, 2, 2, 2, False),
+    ("2x_highres_10b_2p_m1_full", "filters_2x/filters_highres", (2, 1), 10, 2, 1, 2, True),
+    ("2x_lowres_8b_2p_m1_avx2", "filters_2x/filters_lowres", (2, 1), 8, 2, 1, 1, False),
     # asm 5 = AVX512-FP16 pipeline (binary16 arithmetic); BASELINE config 4 is the last one
     ("2x_highres_8b_1p_fp16", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 5, False),
     ("2x_highres_8b_2p_m1_fp16", "filters_2x/filters_highres", (2, 1), 8, 2, 1, 5, False),

@@ -106,3 +106,28 @@ def test_small_and_odd_geometries(size, ratio, fold):
         ref = _oracle(y, case)
         got, _ = _gpu(y, case)
         assert np.array_equal(ref, got), (size, asm, int((ref != got).sum()))
+
+
+def test_device_planes_with_row_pitch():
+    """raisr_hip_process_y_device with pitches larger than the row (device-resident frames inside bigger
+    surfaces): only the addressed pixels are read/written."""
+    import raisr_hip as R
+    import synth
+    import torch
+    for bits in (8, 10):
+        w, h = 100, 60
+        dt = torch.uint8 if bits == 8 else torch.uint16
+        y = synth.natural_y(w, h, bits, seed=21)
+        src = torch.zeros((h, w + 28), dtype=dt, device="cuda")
+        src[:, :w] = torch.from_numpy(y).cuda()
+        dst = torch.full((2 * h, 2 * w + 56), 7, dtype=dt, device="cuda")
+        dev = R.RaisrDevice(0)
+        dev.set_model_from_folder(folder("filters_2x/filters_highres"), bits, 1)
+        dev.configure(w, h, 2 * w, 2 * h, bits=bits)
+        bps = 1 if bits == 8 else 2
+        dev.process_y(src.data_ptr(), (w + 28) * bps, dst.data_ptr(), (2 * w + 56) * bps, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dev.close()
+        out = dst.cpu().numpy()
+        ref = _oracle(y, ("x", "filters_2x/filters_highres", (2, 1), bits, 1, 1, 2, False))
+        assert np.array_equal(out[:, :2 * w], ref) and np.all(out[:, 2 * w:] == 7)
