@@ -99,6 +99,13 @@ int raisr_hip_process_y_device(raisr_hip_ctx *ctx, const void *d_in, size_t in_p
 /* cheap upscale of one plane (chroma path of RNLProcess): src/dst sample type from `bits` */
 int raisr_hip_resize_plane_device(raisr_hip_ctx *ctx, const void *d_src, int sw, int sh, size_t spitch,
                                   void *d_dst, int dw, int dh, size_t dpitch, int bits, void *stream);
+/* Whole device-resident frame: RAISR on Y plus the cheap upscale of both chroma planes (RNLProcess's work,
+ * Raisr.cpp:1369-1389) without leaving HBM -- the zero-copy analogue of ffmpeg/vf_raisr_opencl.c. */
+int raisr_hip_process_frame_device(raisr_hip_ctx *ctx,
+                                   const void *d_in_y, size_t in_y_pitch, void *d_out_y, size_t out_y_pitch,
+                                   const void *d_in_u, const void *d_in_v, size_t in_c_pitch,
+                                   void *d_out_u, void *d_out_v, size_t out_c_pitch,
+                                   int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h, void *stream);
 /* Host planes in, host planes out (what RNLProcess hands over): stages through pinned memory,
  * runs Y + both chroma planes, synchronous.  Chroma pointers may be NULL to skip chroma. */
 int raisr_hip_process_host(raisr_hip_ctx *ctx,

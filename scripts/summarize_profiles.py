@@ -24,7 +24,7 @@ def short(name):
 
 
 lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --steps 20 --warmup 3` (1080p->4K 2x, highres, 1-pass, 3 lanes x 24 frames/step)", ""]
-f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+f = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # newest run first
 if f:
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(f[0])):
@@ -39,7 +39,7 @@ if os.path.exists(ev):
         lines += [f"(bench_events.json unreadable: {e})", ""]
 pmc = {}
 for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_l2"):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -88,3 +88,28 @@ def test_loud_failures():
     with pytest.raises(RuntimeError, match="8-bit"):
         dev.configure(64, 64, 128, 128, bits=10, hash_variant=R.HASH_FP16)
     dev.close()
+
+
+def test_device_resident_yuv_frame_matches_host_path():
+    import raisr_hip as R
+    import synth
+    import torch
+    w, h = 128, 72
+    y = synth.natural_y(w, h, 8, seed=31)
+    u = synth.random_y(w // 2, h // 2, 8, seed=32)
+    v = synth.random_y(w // 2, h // 2, 8, seed=33)
+    dev = R.RaisrDevice(0)
+    dev.set_model_from_folder(folder("filters_2x/filters_highres"), 8, 1)
+    dev.configure(w, h, 2 * w, 2 * h)
+    oy = np.zeros((2 * h, 2 * w), np.uint8); ou = np.zeros((h, w), np.uint8); ov = np.zeros((h, w), np.uint8)
+    dev.process_host(y, oy, u, ou, v, ov)
+    t = lambda a: torch.from_numpy(a).cuda()
+    dy, du, dv = t(y), t(u), t(v)
+    doy = torch.zeros((2 * h, 2 * w), dtype=torch.uint8, device="cuda")
+    dou, dov = torch.zeros((h, w), dtype=torch.uint8, device="cuda"), torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    dev.process_frame(dy.data_ptr(), w, doy.data_ptr(), 2 * w, du.data_ptr(), dv.data_ptr(), w // 2,
+                      dou.data_ptr(), dov.data_ptr(), w, w // 2, h // 2, w, h, s.cuda_stream)
+    s.synchronize()
+    dev.close()
+    assert np.array_equal(doy.cpu().numpy(), oy) and np.array_equal(dou.cpu().numpy(), ou) and np.array_equal(dov.cpu().numpy(), ov)

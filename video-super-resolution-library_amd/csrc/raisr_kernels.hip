@@ -1153,6 +1153,23 @@ int raisr_hip_resize_plane_device(raisr_hip_ctx* c, const void* d_src, int sw, i
     return RAISR_HIP_OK;
 }
 
+// Whole device-resident yuv frame (the zero-copy analogue of the reference's vf_raisr_opencl path): RAISR on Y,
+// cheap upscale on both chroma planes, all enqueued on `stream`.
+int raisr_hip_process_frame_device(raisr_hip_ctx* c,
+                                   const void* d_in_y, size_t in_y_pitch, void* d_out_y, size_t out_y_pitch,
+                                   const void* d_in_u, const void* d_in_v, size_t in_c_pitch,
+                                   void* d_out_u, void* d_out_v, size_t out_c_pitch,
+                                   int cin_w, int cin_h, int cout_w, int cout_h, void* stream)
+{
+    if (!c || !d_in_u || !d_in_v || !d_out_u || !d_out_v) return fail(RAISR_HIP_EINVAL, "null plane");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    int rc = raisr_hip_process_y_device(c, d_in_y, in_y_pitch, d_out_y, out_y_pitch, stream);
+    if (rc) return rc;
+    rc = raisr_hip_resize_plane_device(c, d_in_u, cin_w, cin_h, in_c_pitch, d_out_u, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+    if (rc) return rc;
+    return raisr_hip_resize_plane_device(c, d_in_v, cin_w, cin_h, in_c_pitch, d_out_v, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+}
+
 int raisr_hip_synchronize(raisr_hip_ctx* c)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");

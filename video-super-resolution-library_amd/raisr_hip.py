@@ -85,6 +85,9 @@ def lib():
                                                  ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_resize_plane_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        L.raisr_hip_process_frame_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.raisr_hip_process_host.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
         L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -262,6 +265,10 @@ class RaisrDevice:
     def resize_plane(self, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream=None):
         _check(lib().raisr_hip_resize_plane_device(self._h, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream),
                "raisr_hip_resize_plane_device")
+
+    def process_frame(self, d_y, y_pitch, d_oy, oy_pitch, d_u, d_v, c_pitch, d_ou, d_ov, oc_pitch, cw, ch, ocw, och, stream=None):
+        _check(lib().raisr_hip_process_frame_device(self._h, d_y, y_pitch, d_oy, oy_pitch, d_u, d_v, c_pitch, d_ou, d_ov, oc_pitch,
+                                                    cw, ch, ocw, och, stream), "raisr_hip_process_frame_device")
 
     def process_host(self, y, oy, u=None, ou=None, v=None, ov=None):
         def pp(a):
