@@ -4,9 +4,9 @@
 // Pipeline per RAISR pass (whole-frame semantics of the reference's processSegment(),
 // Library/Raisr.cpp:890-1289, run with threadcount=1):
 //
-//   k_resize   cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)      in  -> LR (u16)
+//   k_resize   cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)      in  -> LR (sample type)
 //   k_hash     11x11 structure tensor + hash  (Raisr_AVX512.cpp:69-131,175-258;
-//              tail columns also Raisr_AVX256.cpp:393-472)                          LR  -> hash (u16)
+//              tail columns also Raisr_AVX256.cpp:393-472)                          LR  -> hash (u8) [+ tail re-hash]
 //   k_filter   hash-indexed 121-tap filter + accept test (Raisr_AVX512.cpp:134-149,
 //              Raisr.cpp:1196-1200)                                                 LR,hash -> HR (f32)
 //   k_blend    census-transform blend, clamp, narrow, borders
@@ -17,8 +17,12 @@
 // with -ffp-contract=off and without fast-math; FMAs appear only where the reference has an
 // explicit fmadd intrinsic.
 //
+// (raisr_fp16_kernels.h holds the binary16 twins k_hash16 / k_filter16 / k_blend16 for the AVX512-FP16 numerics;
+//  k_blend_rand is the Randomness blending mode shared by both.)
+//
 // Design notes (MI355X): the work is fp32-VALU bound (~1 kFLOP per output pixel per pass against
-// ~1.25 compulsory HBM bytes), so the kernels are organised around VALU/LDS efficiency:
+// ~1.25 compulsory HBM bytes) and, in the filter stage, vector-L1 bound (512 B of coefficients per pixel),
+// so the kernels are organised around VALU/LDS/L1 efficiency and occupancy:
 //   * k_hash: one wave = 64 adjacent columns x R rows; gradients are computed once per tile into
 //     LDS as (gx,gy) float2 so the inner loop is ds_read_b64 + v_pk_mul_f32 + v_pk_fma_f32 +
 //     v_fmac_f32 per (pixel, tap) with the Gaussian weight in an SGPR; column accumulators are
@@ -33,7 +37,6 @@
 #include <string.h>
 #include <string>
 #include <vector>
-#include <mutex>
 
 #include "../../include/raisr_hip.h"
 #include "x86_approx_tables.h"
@@ -73,6 +76,7 @@ struct PassParams {
     int randomness;              // 1: BlendingMode Randomness (tail re-hash candidate replaces, never keeps, the first)
     float qangle, qs0, qs1, qc0, qc1;
     const float* bank;           // [hash][type][128]
+    int bank_bytes;              // size of the fp32 bank (buffer-descriptor range)
     const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
     const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
 };
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
 
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
     const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P.bank), 0, 216 * 4 * kTapsPad * (int)sizeof(float), 0x00020000);
+        const_cast<float*>(P.bank), 0, P.bank_bytes, 0x00020000);
     const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
     const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
 
@@ -809,6 +813,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.qs0 = m.h.qstr[0]; P.qs1 = m.h.qstr[1];
     P.qc0 = m.h.qcoh[0]; P.qc1 = m.h.qcoh[1];
     P.bank = (const float*)((const char*)m.blob + kBlobHeader);
+    P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
     P.tab14 = c->d_tab14;
     P.lut_legacy = c->d_lut;
     return P;
@@ -900,6 +905,7 @@ void free_scratch(raisr_hip_ctx* c)
 extern "C" {
 
 const char* raisr_hip_last_error(void) { return g_err.c_str(); }
+void raisr_hip_destroy(raisr_hip_ctx* c);
 const char* raisr_hip_version(void) { return "raisr-hip 0.1 (gfx950)"; }
 
 int raisr_hip_device_count(void)
@@ -909,16 +915,8 @@ int raisr_hip_device_count(void)
     return n;
 }
 
-int raisr_hip_create(raisr_hip_ctx** out, int device_index)
+static int create_impl(raisr_hip_ctx* c)
 {
-    if (!out) return fail(RAISR_HIP_EINVAL, "null out");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail(RAISR_HIP_ENODEV, "no HIP device visible", e);
-    if (device_index < 0 || device_index >= n) return fail(RAISR_HIP_EINVAL, "device index out of range");
-    HIP_TRY(hipSetDevice(device_index));
-    raisr_hip_ctx* c = new raisr_hip_ctx();
-    c->device = device_index;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     // small shared tables
@@ -942,6 +940,22 @@ int raisr_hip_create(raisr_hip_ctx** out, int device_index)
                 c->gauss16.wT[k][i] = (uint32_t)u | ((uint32_t)u << 16);
             }
     }
+    return RAISR_HIP_OK;
+}
+
+
+int raisr_hip_create(raisr_hip_ctx** out, int device_index)
+{
+    if (!out) return fail(RAISR_HIP_EINVAL, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RAISR_HIP_ENODEV, "no HIP device visible", e);
+    if (device_index < 0 || device_index >= n) return fail(RAISR_HIP_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device_index));
+    raisr_hip_ctx* c = new raisr_hip_ctx();
+    c->device = device_index;
+    const int rc = create_impl(c);
+    if (rc != RAISR_HIP_OK) { const std::string keep = g_err; raisr_hip_destroy(c); g_err = keep; return rc; }
     *out = c;
     return RAISR_HIP_OK;
 }
@@ -953,7 +967,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->timer.pool) if (e) (void)hipEventDestroy(e);
     free_scratch(c);
-    for (int i = 0; i < 2; i++) if (c->model[i].blob) hipFree(c->model[i].blob);
+    for (int i = 0; i < 2; i++) if (c->model[i].blob) (void)hipFree(c->model[i].blob);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
@@ -1011,7 +1025,8 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     BlobHeader h{};
     HIP_TRY(hipMemcpyAsync(&h, device_blob, sizeof h, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (h.magic != kBlobMagic || raisr_hip_model_blob_bytes(h.hashkeys, h.pixel_types) != bytes)
+    if (h.magic != kBlobMagic || h.hashkeys <= 0 || h.hashkeys > 255 || (h.pixel_types != 1 && h.pixel_types != 4) ||
+        raisr_hip_model_blob_bytes(h.hashkeys, h.pixel_types) != bytes)
         return fail(RAISR_HIP_EINVAL, "model blob corrupted");
     ModelDev& m = c->model[pass_index];
     if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
