@@ -199,13 +199,10 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 //   v negative (not NaN)       -> rsqrt14 gives the QNaN indefinite, rcp14 passes it through.
 // Positive denormals, +inf and NaN inputs (never produced by 8/10-bit content) take the
 // generic models of x86_approx_dev.h behind a rarely-taken branch.
-// out-of-line: executed only for inputs the hash never produces, keeps the hot kernel small
-__device__ __attribute__((noinline)) uint32_t sqrt14_generic(float v, const uint2* tab)
-{
-    return __float_as_uint(x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab));
-}
-
-__device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab)
+// Fully branch-free: inputs outside the three cases above set `rare` and the caller recomputes that
+// pixel with the generic models (x86_approx_dev.h) -- so the hashes of a lane's pixels are straight-line
+// code the scheduler can interleave.
+__device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab, bool& rare)
 {
     const uint32_t x = __float_as_uint(v);
     const bool normal = (x - 0x00800000u) < 0x7f000000u;
@@ -214,38 +211,46 @@ __device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab)
     uint32_t m = xs & 0x7fffffu;
     const int ue = E - 127, p = ue & 1, half = (ue - p) >> 1;
     uint2 c = tab[64 + 32 * p + (m >> 18)];
-    uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;
-    uint32_t y = ((uint32_t)(126 - half) << 23) | (code << 7);
-    y = ((p | m) == 0) ? ((uint32_t)(127 - half) << 23) : y;               // exact power of four
-    const int Ey = (int)(y >> 23);                                         // rcp14 of the (normal) intermediate
-    m = y & 0x7fffffu;
-    c = tab[m >> 17];
-    code = (c.x - c.y * ((m >> 7) & 1023u)) >> 9;
-    uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code << 7);
-    z = (m == 0) ? ((uint32_t)(254 - Ey) << 23) : z;
-    if (!normal) {
-        if ((x << 1) == 0u) z = x;                                          // +-0
-        else if ((x & 0x80000000u) && (x << 1) <= 0xff000000u) z = 0xffc00000u;   // negative, not NaN
-        else z = sqrt14_generic(v, tab);
-    }
+    uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;                 // rsqrt14 mantissa code (16 bits)
+    const bool pow4 = (p | m) == 0;                                         // exact power of four -> exact power of two
+    // rcp14 of the (normal) intermediate y = 2^(-half-1) * (1 + code/65536)  [or 2^-half when pow4]:
+    // its top 6 / next 10 mantissa bits are code>>10 / code&1023, so y never has to be assembled
+    const int Ey = pow4 ? 127 - half : 126 - half;
+    code = pow4 ? 0u : code;
+    c = tab[code >> 10];
+    const uint32_t code2 = (c.x - c.y * (code & 1023u)) >> 9;
+    uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code2 << 7);
+    z = (code == 0u) ? ((uint32_t)(254 - Ey) << 23) : z;
+    const bool zero = (x << 1) == 0u;                                       // +-0 -> rcp14(+-inf) = +-0
+    const bool negative = (x & 0x80000000u) != 0u && (x << 1) <= 0xff000000u && !zero;   // -> QNaN indefinite
+    z = normal ? z : (zero ? x : 0xffc00000u);
+    rare |= !(normal | zero | negative);
     return __uint_as_float(z);
 }
 
-template <bool LEGACY>
-__device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut)
+// Hash thresholds, passed BY VALUE (SGPRs): taking PassParams by reference in an out-of-line function would
+// force the whole struct into scratch memory.
+struct HashQ { float qangle, qs0, qs1, qc0, qc1; const uint16_t* lut; };
+
+// MODE 0: AVX-512 flavour, branch-free fast path (sets `rare` when the generic model is needed);
+// MODE 1: AVX2 flavour (legacy LUT instructions); MODE 2: AVX-512 flavour, generic models.
+template <int MODE>
+__device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut, bool& rare)
 {
-    if (LEGACY) return x86dev::rcp_legacy(x86dev::rsqrt_legacy(v, lut + 2048), lut);
-    return sqrt14_fast(v, tab);
+    if (MODE == 1) return x86dev::rcp_legacy(x86dev::rsqrt_legacy(v, lut + 2048), lut);
+    if (MODE == 2) return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+    return sqrt14_fast(v, tab, rare);
 }
 
-template <bool LEGACY>
-__device__ __forceinline__ int hash_px(float a, float b, float d, const PassParams& P, const uint2* tab)
+template <int MODE>
+__device__ __forceinline__ int hash_px_impl(float a, float b, float d, const HashQ P, const uint2* tab, bool& rare)
 {
+    constexpr bool LEGACY = MODE == 1;
     const float pi = 3.141592653f;                       // Raisr_globals.h:29
     const float T = a + d;
     const float Dt = (a * d) - (b * b);
     const float rad = ((T * T) * 0.25f) - Dt;            // x/4 == x*0.25 exactly
-    const float s = sqrt_approx<LEGACY>(rad, tab, P.lut_legacy);
+    const float s = sqrt_approx<MODE>(rad, tab, P.lut, rare);
     const float hT = T * 0.5f;                           // T/2
     const float L1 = hT + s;
     const float L2 = hT - s;
@@ -265,8 +270,8 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
     const float nang = -1.0f * ang;
     ang = (b < 0.0f) ? nang : ang;
     ang = ang + ((ang < 0.0f) ? pi : 0.0f);
-    const float sL1 = sqrt_approx<LEGACY>(L1, tab, P.lut_legacy);
-    const float sL2 = sqrt_approx<LEGACY>(L2, tab, P.lut_legacy);
+    const float sL1 = sqrt_approx<MODE>(L1, tab, P.lut, rare);
+    const float sL2 = sqrt_approx<MODE>(L2, tab, P.lut, rare);
     const float coh = (sL1 - sL2) / ((sL1 + sL2) + 1e-17f);
     const float str = L1;
     const float fl = __builtin_floorf(ang * P.qangle);
@@ -281,6 +286,18 @@ __device__ __forceinline__ int hash_px(float a, float b, float d, const PassPara
         ci = 2 - ((int)(coh <= P.qc0) + (int)(coh <= P.qc1));
     }
     return ai * 9 + si * 3 + ci;
+}
+
+// out-of-line slow paths (kept out of the hot straight-line code)
+__device__ __attribute__((noinline)) int hash_px_generic(float a, float b, float d, const HashQ P, const uint2* tab)
+{
+    bool unused = false;
+    return hash_px_impl<2>(a, b, d, P, tab, unused);
+}
+__device__ __attribute__((noinline)) int hash_px_legacy(float a, float b, float d, const HashQ P, const uint2* tab)
+{
+    bool unused = false;
+    return hash_px_impl<1>(a, b, d, P, tab, unused);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,20 +391,37 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     }
 
     const int c = c0 + lane;
+    f2 ad[R];
+    float bb[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        ad[j] = (holdAD[j] + curAD[j]) + t1AD[j];            // (Gb+Gc) + (Ga+Gd)
+        bb[j] = (holdB[j] + curB[j]) + t1B[j];
+    }
+    // AVX-512 flavour for every pixel of the lane as straight-line code (independent chains interleave);
+    // the rare cases -- generic approximation-instruction inputs, AVX2 flavour of the tail columns -- follow.
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    unsigned h1[R];
+    bool rare[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) { h1[j] = 0xFFu; rare[j] = false; }
+    if (P.a_end > P.a_begin) {                               // kernel-uniform
+#pragma unroll
+        for (int j = 0; j < R; j++) h1[j] = (unsigned)hash_px_impl<0>(ad[j].x, bb[j], ad[j].y, HQ, sTab, rare[j]);
+    }
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const int r = r0 + w * R + j;
-        const f2 ad = (holdAD[j] + curAD[j]) + t1AD[j];      // (Gb+Gc) + (Ga+Gd)
-        const float bb = (holdB[j] + curB[j]) + t1B[j];
         if (r < P.H - kMargin && c < P.c_final) {
-            // first hash: AVX-512 flavour inside its column range, else the AVX2 one (AVX2 mode / no 16-wide chunk)
-            const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
-            unsigned h1 = 0xFFu;
-            if (inA) h1 = (unsigned)hash_px<false>(ad.x, bb, ad.y, P, sTab);
-            else if (inB) h1 = (unsigned)hash_px<true>(ad.x, bb, ad.y, P, sTab);
-            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)h1;
-            if (inA && inB)                                         // tail columns re-hashed by the AVX2 routine
-                hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hash_px<true>(ad.x, bb, ad.y, P, sTab);
+            unsigned h = h1[j];
+            if (rare[j]) h = (unsigned)hash_px_generic(ad[j].x, bb[j], ad[j].y, HQ, sTab);
+            if (inB) {                                       // AVX2 mode, or the tail columns of AVX-512 mode
+                const unsigned hB = (unsigned)hash_px_legacy(ad[j].x, bb[j], ad[j].y, HQ, sTab);
+                if (inA) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;   // re-hashed tail column
+                else h = hB;
+            }
+            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)(inA || inB ? h : 0xFFu);
         }
     }
 }
