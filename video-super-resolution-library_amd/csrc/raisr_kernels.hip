@@ -503,11 +503,10 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         float keep = 0.0f;
-        bool anyB = false;
+        const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
 #pragma unroll 4
         for (int s = 0; s < 16; s++) {          // unroll 4 measured best (1: same, 8/16: slower -- code size / occupancy)
             const unsigned hA = sH[prow * TW + 4 * s + g];
-            anyB |= sH2[prow * TW + 4 * s + g] != 0xFFu;
             float res = RAISR_LDS_F(ctr, s);
             if (hA != 0xFFu) {
                 const unsigned voff = hA * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
