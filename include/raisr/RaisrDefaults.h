@@ -10,49 +10,55 @@
 #ifndef RAISR_DEFAULTS_H
 #define RAISR_DEFAULTS_H
 
-#define defaultPatchSize (11)
-static const unsigned int defaultPatchAreaSize = defaultPatchSize * defaultPatchSize;
-
-/* One image plane.  `step` is the byte distance between rows and may exceed width*bytes. */
-typedef struct VideoDataType {
-    unsigned char *pData;
-    unsigned int   width;
-    unsigned int   height;
-    unsigned int   step;
-    unsigned int   bitShift;   /* unused by this backend (as on the reference's CPU path) */
-} VideoDataType;
-
+/* ---- status codes returned by every RNL* / RNLHandler_* call --------------------------------- */
 typedef enum RNLERRORTYPE {
     RNLErrorNone                  = 0,
-    RNLErrorInsufficientResources = (int)0x80001000,
-    RNLErrorUndefined             = (int)0x80001001,
-    RNLErrorBadParameter          = (int)0x80001002,
+    RNLErrorInsufficientResources = (int)0x80001000,   /* host or HBM allocation failed          */
+    RNLErrorUndefined             = (int)0x80001001,   /* HIP runtime / launch failure           */
+    RNLErrorBadParameter          = (int)0x80001002,   /* rejected argument or missing model file */
     RNLErrorMax                   = (int)0x7FFFFFFF
 } RNLERRORTYPE;
 
-typedef enum BlendingMode {
-    Randomness         = 1,
-    CountOfBitsChanged = 2
-} BlendingMode;
-
+/* ---- which numerics the GPU reproduces (the reference's "asm" option) ------------------------ */
 typedef enum ASMType {
-    AVX2           = 1,   /* GPU reproduces the AVX2 path's output            */
-    AVX512         = 2,   /* GPU reproduces the AVX-512 fp32 path's output    */
-    OpenCL         = 3,   /* rejected: no OpenCL in this build                */
-    OpenCLExternal = 4,   /* rejected                                         */
-    AVX512_FP16    = 5,   /* GPU reproduces the AVX512-FP16 path (8-bit)      */
-    HIP            = 6    /* appended: MI355X backend, AVX-512 fp32 numerics  */
+    AVX2           = 1,   /* AVX2 path's output (RCPPS/RSQRTPS-based hashing)           */
+    AVX512         = 2,   /* AVX-512 fp32 path's output (VRCP14/VRSQRT14-based hashing) */
+    OpenCL         = 3,   /* rejected: no OpenCL in this build                          */
+    OpenCLExternal = 4,   /* rejected                                                   */
+    AVX512_FP16    = 5,   /* AVX512-FP16 path's output (binary16 pipeline, 8-bit only)  */
+    HIP            = 6    /* appended: MI355X backend, AVX-512 fp32 numerics            */
 } ASMType;
 
+/* ---- sample range: VideoRange clamps to [16,235]<<(bits-8), FullRange to [0,2^bits-1] -------- */
+typedef enum RangeType {
+    VideoRange = 1,
+    FullRange  = 2
+} RangeType;
+
+/* ---- how the filtered and the cheap-upscaled planes are merged ------------------------------- */
+typedef enum BlendingMode {
+    Randomness         = 1,   /* 3x3 census "randomness" weight between the two planes */
+    CountOfBitsChanged = 2    /* census bits changed -> per-pixel weight (default)      */
+} BlendingMode;
+
+/* Kept for source compatibility; the HIP backend does not look at the host CPU vendor. */
 typedef enum MachineVendorType {
     INTEL              = 1,
     AMD                = 2,
     VENDOR_UNSUPPORTED = 3
 } MachineVendorType;
 
-typedef enum RangeType {
-    VideoRange = 1,
-    FullRange  = 2
-} RangeType;
+/* ---- one image plane; `step` = bytes between rows (may exceed width * bytes per sample) ------ */
+typedef struct VideoDataType {
+    unsigned char *pData;      /* host pointer, caller-owned                                     */
+    unsigned int   width;      /* samples per row                                                */
+    unsigned int   height;     /* rows                                                           */
+    unsigned int   step;
+    unsigned int   bitShift;   /* unused by this backend (as on the reference's CPU path)        */
+} VideoDataType;
+
+/* ---- filter geometry: 11x11 patch, 121 taps --------------------------------------------------- */
+#define defaultPatchSize (11)
+static const unsigned int defaultPatchAreaSize = defaultPatchSize * defaultPatchSize;
 
 #endif /* RAISR_DEFAULTS_H */

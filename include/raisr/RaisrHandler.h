@@ -4,11 +4,11 @@
  * Same names, argument order and meaning; implemented in csrc/raisr_api.cpp on top of the
  * raisr_hip_* device ABI (include/raisr_hip.h).
  *
- *   Init     once; loads <modelPath>/{config,filterbin_2_<bits>[_2],Qfactor_*}
+ *   Init     once; loads <filterFolder>/{config,filterbin_2_<bits>[_2],Qfactor_*}
  *   SetRes   once, with the first frame's plane descriptors (sizes/steps only)
  *   Process  per frame, synchronous; caller owns every buffer; host planes in, host planes out
  *   SetOpenCLContext(NULL, NULL, platform, device): kept as the device-selection hook --
- *            `deviceIndex` is the HIP device ordinal; call before Init
+ *            `deviceOrdinal` is the HIP device ordinal; call before Init
  *   Deinit   releases device and host resources
  */
 #ifndef RAISR_HANDLER_H
@@ -20,20 +20,25 @@
 extern "C" {
 #endif
 
-RNLERRORTYPE RNLHandler_Init(const char *modelPath, float ratio, unsigned int bitDepth,
-                             RangeType rangeType, unsigned int threadCount, ASMType asmType,
-                             unsigned int passes, unsigned int twoPassMode);
+/* -> RNLInit (Raisr.h); the C string is copied. */
+RNLERRORTYPE RNLHandler_Init(const char *filterFolder, float upscaleRatio, unsigned int sampleBits,
+                             RangeType range, unsigned int workers, ASMType numerics,
+                             unsigned int numPasses, unsigned int passMode);
 
-RNLERRORTYPE RNLHandler_SetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *inCb,
-                               VideoDataType *outY, VideoDataType *outCr, VideoDataType *outCb);
+/* -> RNLSetRes */
+RNLERRORTYPE RNLHandler_SetRes(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
+                               VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb);
 
-RNLERRORTYPE RNLHandler_Process(VideoDataType *inY, VideoDataType *inCr, VideoDataType *inCb,
-                                VideoDataType *outY, VideoDataType *outCr, VideoDataType *outCb,
-                                BlendingMode blendingMode);
+/* -> RNLProcess */
+RNLERRORTYPE RNLHandler_Process(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
+                                VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb,
+                                BlendingMode blend);
 
-RNLERRORTYPE RNLHandler_SetOpenCLContext(void *context, void *device_id, int platformIndex,
-                                         int deviceIndex);
+/* -> RNLSetOpenCLContext */
+RNLERRORTYPE RNLHandler_SetOpenCLContext(void *clContext, void *clDevice, int platformOrdinal,
+                                         int deviceOrdinal);
 
+/* -> RNLDeinit */
 RNLERRORTYPE RNLHandler_Deinit(void);
 
 #ifdef __cplusplus
