@@ -123,7 +123,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set) -> always go through RCCL, even with one rank, so the
+    # collective path of the N-GPU runs is the one exercised by a 1-GPU torchrun smoke test
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- model: rank 0 reads the files and packs the device blob; RCCL broadcast to the others ----
@@ -136,7 +139,7 @@ def main():
             bank, qstr, qcoh, qa = R.read_model_folder(FOLDER, bits, p + 1)
             host_blob = R.pack_model_blob(bank, qstr, qcoh, qa)
         nbytes = R.lib().raisr_hip_model_blob_bytes(216, CFG["pixel_types"])
-        blobs.append(sharding.broadcast_model_blob(host_blob, nbytes, dev, dist if world > 1 else None))
+        blobs.append(sharding.broadcast_model_blob(host_blob, nbytes, dev, dist if use_dist else None))
     torch.cuda.synchronize()
 
     lanes = []
@@ -170,7 +173,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +189,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, dev, dist if world > 1 else None)
+    dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
 
     # per-kernel event timings (rank 0's lanes)
     kern = {}
@@ -244,7 +247,7 @@ def main():
 
     for d in lanes:
         d.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

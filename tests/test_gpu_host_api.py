@@ -113,3 +113,4 @@ def test_device_resident_yuv_frame_matches_host_path():
     s.synchronize()
     dev.close()
     assert np.array_equal(doy.cpu().numpy(), oy) and np.array_equal(dou.cpu().numpy(), ou) and np.array_equal(dov.cpu().numpy(), ov)
+

@@ -22,7 +22,7 @@ def broadcast_model_blob(blob, nbytes, device, dist=None, src=0):
         assert t.numel() == nbytes
     else:
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():   # also with one rank: same code path as N ranks
         dist.broadcast(t, src=src)
     return t
 
@@ -30,7 +30,7 @@ def broadcast_model_blob(blob, nbytes, device, dist=None, src=0):
 def max_over_ranks(value, device, dist=None):
     """MAX-reduce a python float over ranks (bench timing contract)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
