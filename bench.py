@@ -42,6 +42,9 @@ def parse():
 
 
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
+VALU_FP32_PEAK_TFLOPS = 78.6                                 # non-packed fp32 FMA peak (157.3 is the packed figure)
+# SURVEY.md s8d per-filtered-pixel FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add, hash ~60
+HASH_FLOP_PER_PIXEL = 121 * (2 + 6) + 45 + 60
 
 # BASELINE.json configs.  The bench line is C2 (configs[1]); the others are selectable for
 # profiling: (in_w, in_h, out_w, out_h, folder, bits, passes, mode, hash variant, description)
@@ -200,6 +203,17 @@ def main():
                 e["total_ms"] += v["total_ms"]; e["count"] += v["count"]
             d.timing_enable(False)
 
+    # isolated per-kernel durations: the same frames on ONE lane after the timed region (no other kernel
+    # shares the chip), so a launch's duration is its own -- the overlapped average above is not
+    iso = {}
+    if timing and rank == 0:
+        lanes[0].timing_enable(True)
+        for f in range(2 * uniq):
+            lanes[0].process_y(d_in[f % uniq].data_ptr(), IN_W * bps, d_out[0].data_ptr(), OUT_W * bps)
+        torch.cuda.synchronize()
+        iso = {k: v["total_ms"] / max(1, v["count"]) for k, v in lanes[0].timing_read().items()}
+        lanes[0].timing_enable(False)
+
     frames_total = args.steps * nf * world
     mp_s = OUT_W * OUT_H * frames_total / dt / 1e6
 
@@ -222,8 +236,23 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                         "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": int(algo_per_launch),
+                        "lanes_overlapped": args.lanes,
                         "note": "path is fp32-VALU bound (~1 kFLOP per output pixel vs 1.25 compulsory bytes); "
                                 "HBM fraction is reported as required, VALU utilisation is the binding figure (DESIGN.md)"}
+            if dom in iso and iso[dom] > 0:
+                # the binding resource: fp32 VALU.  Filtered zone of one launch x the s8d FLOP model / isolated duration
+                c_final = 6 + 8 * ((OUT_W - 12) // 8)
+                zone_w, zone_h = c_final - 6, OUT_H - 12
+                if CFG["mode"] == 2 and passes == 2:         # pass 1 of mode 2 runs at input size; average the two launches
+                    c1 = 6 + 8 * ((IN_W - 12) // 8)
+                    px = ((c1 - 6) * (IN_H - 12) + zone_w * zone_h) / 2
+                else:
+                    px = zone_w * zone_h
+                tflops = px * HASH_FLOP_PER_PIXEL / (iso[dom] * 1e-3) / 1e12
+                roofline["valu"] = {"kernel": dom, "isolated_launch_ms": round(iso[dom], 4),
+                                    "flop_per_launch": int(px * HASH_FLOP_PER_PIXEL), "achieved": round(tflops, 2),
+                                    "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s (fp32 VALU)",
+                                    "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -240,6 +269,7 @@ def main():
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "parallelism": f"frame-shard x{world}"},
             "kernels_avg_ms": kernels_ms,
+            "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
