@@ -42,7 +42,9 @@ def parse():
 
 
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
-VALU_FP32_PEAK_TFLOPS = 78.6                                 # non-packed fp32 FMA peak (157.3 is the packed figure)
+VALU_FP32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md "Peak FP32 (vector)": 4 SIMD-32 per CU, all-FMA.
+# (scripts/valu_rate_probe.hip sustains 911 G wave-inst/s = 116.6 TFLOP/s of v_fma_f32 on this power-limited part; the
+#  structure tensor's mix of 2 mul + 3 fma per tap can reach at most 1013/(2*605) = 84 % of an all-FMA peak.)
 # SURVEY.md s8d per-filtered-pixel FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add, hash ~60
 HASH_FLOP_PER_PIXEL = 121 * (2 + 6) + 45 + 60
 
