@@ -120,6 +120,13 @@ int raisr_hip_synchronize(raisr_hip_ctx *ctx);
  * filtered zone) and HR plane (fp32; binary16 bit patterns in the low half-words in FP16 mode) of pass
  * `pass_index` to host buffers (either may be NULL). */
 int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash_out, float *hr_out);
+/* Hash bucket (0..215) of `n` host-side structure-tensor triples (a, b, d) x n with pass `pass_index`'s
+ * thresholds, computed by the very device functions the hash kernel runs (fast path plus generic fall-back
+ * for RAISR_HIP_HASH_AVX512; the RCPPS/RSQRTPS flavour for RAISR_HIP_HASH_AVX2).  Replaces nothing in the
+ * reference: it exposes GetHashValue_AVX512_32f_16Elements (Library/Raisr_AVX512.cpp:175-258) and
+ * GetHashValue_AVX256_32f_8Elements (Library/Raisr_AVX256.cpp:393-472) to unit tests on arbitrary inputs. */
+int raisr_hip_debug_hash(raisr_hip_ctx *ctx, int pass_index, int hash_flavour, const float *abd, size_t n,
+                         uint8_t *hash_out);
 /* Per-kernel HIP-event timing of subsequent process calls: events are recorded around every kernel on
  * the stream it is launched on.  _read() returns the number of distinct kernels and fills, per kernel,
  * its name (64 bytes each), the summed milliseconds and the launch count since _enable(ctx, 1);

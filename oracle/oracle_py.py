@@ -41,6 +41,8 @@ def lib():
             getattr(_LIB, n).argtypes = [ctypes.c_float]
         _LIB.ora_hash.restype = ctypes.c_int
         _LIB.ora_hash.argtypes = [ctypes.c_float] * 3 + [ctypes.c_void_p, ctypes.c_int]
+        _LIB.ora_hash_array.restype = None
+        _LIB.ora_hash_array.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     return _LIB
 
 
@@ -189,4 +191,13 @@ def process_y16(plane, out_w, out_h, p1, p2=None, passes=1, mode=1, tie=TIE_HALF
     out = np.zeros((out_h, out_w), dtype=np.uint16)
     lib().ora16_process_y(src.ctypes.data_as(ctypes.c_void_p), w, h, out.ctypes.data_as(ctypes.c_void_p), out_w, out_h,
                           passes, mode, ctypes.byref(p1), ctypes.byref(p2 if p2 is not None else p1), tie)
+    return out
+
+
+def hash_array(abd, p, avx2_variant):
+    """Hash buckets of an (n, 3) float32 array of (a, b, d) triples (oracle hash_pixel)."""
+    abd = np.ascontiguousarray(abd, np.float32)
+    out = np.zeros(abd.shape[0], np.uint8)
+    lib().ora_hash_array(abd.ctypes.data_as(ctypes.c_void_p), abd.shape[0], ctypes.byref(p), int(avx2_variant),
+                         out.ctypes.data_as(ctypes.c_void_p))
     return out

@@ -454,3 +454,8 @@ float ora_x86_rsqrt14(float x) { return x86_rsqrt14(x); }
 float ora_x86_rcp(float x) { return x86_rcp(x); }
 float ora_x86_rsqrt(float x) { return x86_rsqrt(x); }
 int ora_hash(float a, float b, float d, const ora_pass_t *P, int avx2_variant) { return hash_pixel(a, b, d, P, avx2_variant); }
+/* n (a, b, d) triples -> n hash buckets */
+void ora_hash_array(const float *abd, size_t n, const ora_pass_t *P, int avx2_variant, uint8_t *out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = (uint8_t)hash_pixel(abd[3 * i], abd[3 * i + 1], abd[3 * i + 2], P, avx2_variant);
+}

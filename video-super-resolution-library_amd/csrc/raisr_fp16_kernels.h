@@ -149,11 +149,7 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
     for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {     // linear sweep: every lane busy
-        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1), gx = min(max(c0 - 6 + tx, 0), P.W - 1);
-        sL[idx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];                    // exact for 8-bit content
-    }
+    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);   // u8 -> binary16 is exact for 8-bit content
     __syncthreads();
     for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
         const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
@@ -252,11 +248,7 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * (TW + 10)); idx += 256) {   // linear sweep: every lane busy
-        const int ty = (int)(idx / (TW + 10)), tx = (int)(idx - (unsigned)ty * (TW + 10));
-        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1), gx = min(max(c0 - 5 + tx, 0), P.W - 1);
-        sL[ty * LW + tx] = (hf)(float)lr[(size_t)gy * P.lr_pitch + gx];
-    }
+    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
         sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
@@ -321,14 +313,29 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {      // linear sweep: every lane busy
-        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-        const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
-        float Hv = L;                                                               // HR := LR outside the filtered zone
-        if (gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final) Hv = (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]);
-        sL[idx] = L;
-        sHh[idx] = Hv;
+    {   // linear sweep, every lane busy; all LR and HR loads of a thread in flight before the first LDS write
+        constexpr unsigned N = LH * LW, NL = (N + 255u) / 256u;
+        TOut lv[NL];
+        float hv[NL];
+        bool inz[NL];
+#pragma unroll
+        for (unsigned it = 0; it < NL; it++) {
+            const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
+            const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+            const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+            lv[it] = lr[(size_t)gy * P.lr_pitch + gx];
+            inz[it] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
+            hv[it] = inz[it] ? (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]) : 0.0f;
+        }
+#pragma unroll
+        for (unsigned it = 0; it < NL; it++) {
+            const unsigned idx = threadIdx.x + 256u * it;
+            const float L = (float)lv[it];
+            if (idx < N) {
+                sL[idx] = L;
+                sHh[idx] = inz[it] ? hv[it] : L;                                    // HR := LR outside the filtered zone
+            }
+        }
     }
     __syncthreads();
     const int x = c0 + lane;

@@ -189,6 +189,33 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage an LH x LWLOAD window of a plane -- origin (y0, x0), replicate-clamped to the W x H plane --
+// into an LDS tile of row stride LSTRIDE, converting each sample to TL.  Block = 256 threads, linear sweep
+// (every lane busy).  All of a thread's global loads are issued before the first one is consumed: the
+// rolled form waited for each load in turn, i.e. ~9 dependent memory round trips at the head of every
+// workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
+{
+    constexpr unsigned N = LH * LWLOAD, NL = (N + 255u) / 256u;
+    T v[NL];
+#pragma unroll
+    for (unsigned it = 0; it < NL; it++) {
+        const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
+        const int ty = (int)(idx / LWLOAD), tx = (int)(idx - (unsigned)ty * LWLOAD);
+        const int gy = min(max(y0 + ty, 0), H - 1), gx = min(max(x0 + tx, 0), W - 1);
+        v[it] = src[(size_t)gy * pitch + gx];
+    }
+#pragma unroll
+    for (unsigned it = 0; it < NL; it++) {
+        const unsigned idx = threadIdx.x + 256u * it;
+        const int ty = (int)(idx / LWLOAD), tx = (int)(idx - (unsigned)ty * LWLOAD);
+        if (idx < N) sL[ty * LSTRIDE + tx] = (TL)(float)v[it];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
 // (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
 // ------------------------------------------------------------------------------------------------
@@ -205,26 +232,26 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 __device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab, bool& rare)
 {
     const uint32_t x = __float_as_uint(v);
-    const bool normal = (x - 0x00800000u) < 0x7f000000u;
-    const uint32_t xs = normal ? x : 0x3f800000u;                          // keep the table indices in range
-    const int E = (int)(xs >> 23);
-    uint32_t m = xs & 0x7fffffu;
-    const int ue = E - 127, p = ue & 1, half = (ue - p) >> 1;
-    uint2 c = tab[64 + 32 * p + (m >> 18)];
-    uint32_t code = (c.x - c.y * ((m >> 8) & 1023u)) >> 9;                 // rsqrt14 mantissa code (16 bits)
-    const bool pow4 = (p | m) == 0;                                         // exact power of four -> exact power of two
+    // rsqrt14 table row = [exponent parity p][top 5 mantissa bits] = bits 23..18 of x with bit 23 inverted
+    // (p = (E-127)&1 = ~E&1); every bit pattern yields an in-range row, so nothing has to be sanitised first
+    uint2 c = tab[64u + (((x >> 18) & 63u) ^ 32u)];
+    uint32_t code = (c.x - __umul24(c.y, (x >> 8) & 1023u)) >> 9;          // rsqrt14 mantissa code (16 bits); C1*t < 2^26
+    const bool pow4 = (x & 0x00ffffffu) == 0x00800000u;                     // p == 0 && m == 0: exact power of four
+    code = pow4 ? 0u : code;
     // rcp14 of the (normal) intermediate y = 2^(-half-1) * (1 + code/65536)  [or 2^-half when pow4]:
     // its top 6 / next 10 mantissa bits are code>>10 / code&1023, so y never has to be assembled
-    const int Ey = pow4 ? 127 - half : 126 - half;
-    code = pow4 ? 0u : code;
     c = tab[code >> 10];
-    const uint32_t code2 = (c.x - c.y * (code & 1023u)) >> 9;
-    uint32_t z = ((uint32_t)(253 - Ey) << 23) | (code2 << 7);
-    z = (code == 0u) ? ((uint32_t)(254 - Ey) << 23) : z;
-    const bool zero = (x << 1) == 0u;                                       // +-0 -> rcp14(+-inf) = +-0
-    const bool negative = (x & 0x80000000u) != 0u && (x << 1) <= 0xff000000u && !zero;   // -> QNaN indefinite
+    uint32_t code2 = (c.x - __umul24(c.y, code & 1023u)) >> 9;
+    asm volatile("" : "+v"(code2));     // keep the second look-up unconditional: a branch around it would serialise the lane's 12 roots
+    const uint32_t ez = ((x + 0x3f800000u) >> 1) & 0x7f800000u;             // biased exponent (E+127)>>1 of the root
+    // y an exact power of two (code == 0): rcp14 is exact as well -- 2^half for a power of four, else one binade up
+    const uint32_t zp = ez + (pow4 ? 0u : 0x00800000u);
+    uint32_t z = (code == 0u) ? zp : (ez | (code2 << 7));
+    const bool normal = __builtin_amdgcn_classf(v, 0x100);               // +normal
+    const bool zero = __builtin_amdgcn_classf(v, 0x060);                 // +-0 -> rcp14(+-inf) = +-0
+    // -inf, -normal, -denormal -> QNaN indefinite; sNaN, qNaN, +denormal, +inf -> generic model (caller)
     z = normal ? z : (zero ? x : 0xffc00000u);
-    rare |= !(normal | zero | negative);
+    rare |= __builtin_amdgcn_classf(v, 0x283);
     return __uint_as_float(z);
 }
 
@@ -328,11 +355,7 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
 
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {     // linear sweep: every lane busy
-        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-        const int gy = min(max(r0 - 6 + ty, 0), P.H - 1), gx = min(max(c0 - 6 + tx, 0), P.W - 1);
-        sL[idx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
-    }
+    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
     for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
@@ -426,6 +449,29 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     }
 }
 
+// Test hook: the fp32 hash of arbitrary (a, b, d) tensor triples through exactly the code k_hash runs
+// (fast path + generic fall-back for the AVX-512 flavour, or the AVX2 flavour).
+__global__ __launch_bounds__(256) void k_debug_hash(const float* __restrict__ abd, unsigned n, PassParams P, int legacy,
+                                                    uint8_t* __restrict__ out)
+{
+    __shared__ uint2 sTab[128];
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    __syncthreads();
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const float a = abd[3 * (size_t)i], b = abd[3 * (size_t)i + 1], d = abd[3 * (size_t)i + 2];
+    unsigned h;
+    if (legacy) {
+        h = (unsigned)hash_px_legacy(a, b, d, HQ, sTab);
+    } else {
+        bool rare = false;
+        h = (unsigned)hash_px_impl<0>(a, b, d, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px_generic(a, b, d, HQ, sTab);
+    }
+    out[i] = (uint8_t)h;
+}
+
 #include "raisr_fp16_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -464,11 +510,7 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * (TW + 10)); idx += 256) {   // linear sweep: every lane busy
-        const int ty = (int)(idx / (TW + 10)), tx = (int)(idx - (unsigned)ty * (TW + 10));
-        const int gy = min(max(r0 - 5 + ty, 0), P.H - 1), gx = min(max(c0 - 5 + tx, 0), P.W - 1);
-        sL[ty * LW + tx] = (float)lr[(size_t)gy * P.lr_pitch + gx];
-    }
+    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
     for (int ty = w; ty < TH; ty += 4) {
         const int r = r0 + ty, c = c0 + lane;
         const bool in = r < P.H - kMargin && c < P.c_final;
@@ -559,14 +601,29 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(LH * LW); idx += 256) {      // linear sweep: every lane busy
-        const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-        const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-        const float L = (float)lr[(size_t)gy * P.lr_pitch + gx];
-        float Hv = L;                                                               // HR := LR outside the filtered zone
-        if (gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final) Hv = hr[(size_t)gy * P.hr_pitch + gx];
-        sL[idx] = L;
-        sH[idx] = Hv;
+    {   // linear sweep, every lane busy; all LR and HR loads of a thread in flight before the first LDS write
+        constexpr unsigned N = LH * LW, NL = (N + 255u) / 256u;
+        TOut lv[NL];
+        float hv[NL];
+        bool inz[NL];
+#pragma unroll
+        for (unsigned it = 0; it < NL; it++) {
+            const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
+            const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
+            const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
+            lv[it] = lr[(size_t)gy * P.lr_pitch + gx];
+            inz[it] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
+            hv[it] = inz[it] ? hr[(size_t)gy * P.hr_pitch + gx] : 0.0f;
+        }
+#pragma unroll
+        for (unsigned it = 0; it < NL; it++) {
+            const unsigned idx = threadIdx.x + 256u * it;
+            const float L = (float)lv[it];
+            if (idx < N) {
+                sL[idx] = L;
+                sH[idx] = inz[it] ? hv[it] : L;                                     // HR := LR outside the filtered zone
+            }
+        }
     }
     __syncthreads();
     const int x = c0 + lane;
@@ -1285,6 +1342,32 @@ int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint8_t* hash_o
     if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n, hipMemcpyDeviceToHost));
     if (hr_out) HIP_TRY(hipMemcpy(hr_out, c->d_hr[pass_index], n * sizeof(float), hipMemcpyDeviceToHost));
     return RAISR_HIP_OK;
+}
+
+// Test hook: hash bucket of n host-side (a, b, d) triples with pass `pass_index`'s thresholds, computed by the
+// device functions k_hash uses (hash_flavour: RAISR_HIP_HASH_AVX512 or RAISR_HIP_HASH_AVX2).
+int raisr_hip_debug_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, const float* abd, size_t n, uint8_t* hash_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1 || !abd || !hash_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (hash_flavour != RAISR_HIP_HASH_AVX512 && hash_flavour != RAISR_HIP_HASH_AVX2) return fail(RAISR_HIP_EINVAL, "hash_flavour must be AVX512 or AVX2");
+    if (!c->model[pass_index].blob) return fail(RAISR_HIP_ESTATE, "model not set for this pass");
+    if (n == 0) return RAISR_HIP_OK;
+    if (n > 0x7fffffffu / 3) return fail(RAISR_HIP_EINVAL, "too many triples");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, n) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc) {
+        hipLaunchKernelGGL(k_debug_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P,
+                           hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_hash");
+    }
+    if (!rc && hipMemcpy(hash_out, d_out, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
 }
 
 // Enable/disable per-kernel HIP-event timing of subsequent process calls (events are recorded on the

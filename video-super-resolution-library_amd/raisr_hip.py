@@ -92,6 +92,7 @@ def lib():
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
         L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.RNLHandler_Init.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
@@ -291,6 +292,13 @@ class RaisrDevice:
         hs = np.zeros((h, w), np.uint8); hr = np.zeros((h, w), np.float32)
         _check(lib().raisr_hip_debug_read_stage(self._h, pass_index, hs.ctypes.data, hr.ctypes.data), "debug_read_stage")
         return hs, hr
+
+    def debug_hash(self, abd, pass_index=0, flavour=HASH_AVX512):
+        """Hash buckets of an (n, 3) float32 array of structure-tensor triples, via the device hash functions."""
+        abd = np.ascontiguousarray(abd, np.float32)
+        out = np.zeros(abd.shape[0], np.uint8)
+        _check(lib().raisr_hip_debug_hash(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
+        return out
 
     def timing_enable(self, on=True):
         _check(lib().raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
