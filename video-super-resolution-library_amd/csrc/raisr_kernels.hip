@@ -531,12 +531,14 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
         const_cast<float*>(P.bank), 0, P.bank_bytes, 0x00020000);
     const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
     const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
+    const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1
     for (int row = 0; row < 4; row++) {
         const int prow = 4 * w + row;
         const int r = r0 + prow;
         const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kTapsPad * 4) : 0u;
+        const unsigned row_lane_off = trow_off + lane_off;
         // LDS byte addresses of this lane's 8 taps (and the centre pixel) for step 0; step s adds the immediate 16*s
         const char* tap[8];
 #pragma unroll
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
             const unsigned hA = sH[prow * TW + 4 * s + g];
             float res = RAISR_LDS_F(ctr, s);
             if (hA != 0xFFu) {
-                const unsigned voff = hA * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
+                const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
                 float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
             for (int s = 0; s < 16; s++) {
                 const unsigned hB = sH2[prow * TW + 4 * s + g];
                 if (hB == 0xFFu) continue;
-                const unsigned voff = hB * (unsigned)(P.pixel_types * kTapsPad * 4) + trow_off + lane_off;
+                const unsigned voff = __umul24(hB, bank_stride) + row_lane_off;
                 float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
