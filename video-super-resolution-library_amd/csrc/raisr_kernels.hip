@@ -198,20 +198,40 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
 {
-    constexpr unsigned N = LH * LWLOAD, NL = (N + 255u) / 256u;
-    T v[NL];
+    static_assert(LWLOAD > 64 && LWLOAD <= 128, "a tile row is one 64-lane sweep plus a remainder");
+    constexpr int REM = LWLOAD - 64;                    // halo columns right of the first 64
+    constexpr int NM = (LH + 3) / 4;                    // rows per wave in the main part
+    constexpr unsigned NR = LH * REM, NRL = (NR + 255u) / 256u;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the row arithmetic stays scalar
+    __builtin_assume(w >= 0 && w < 4);
+    // main part: wave w sweeps columns [0,64) of rows w, w+4, ...: one clamped column index per lane for all rows
+    const int gxm = min(max(x0 + lane, 0), W - 1);
+    T vm[NM];
 #pragma unroll
-    for (unsigned it = 0; it < NL; it++) {
-        const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
-        const int ty = (int)(idx / LWLOAD), tx = (int)(idx - (unsigned)ty * LWLOAD);
+    for (int it = 0; it < NM; it++) {
+        const int gy = min(max(y0 + min(w + 4 * it, LH - 1), 0), H - 1);
+        vm[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gxm];          // planes are < 2^31 samples: 32-bit offsets
+    }
+    // remainder: the REM right-hand columns of all rows, spread linearly over the block
+    T vr[NRL];
+#pragma unroll
+    for (unsigned it = 0; it < NRL; it++) {
+        const unsigned idx = min(threadIdx.x + 256u * it, NR - 1u);
+        const int ty = (int)(idx / REM), tx = 64 + (int)(idx - (unsigned)ty * REM);
         const int gy = min(max(y0 + ty, 0), H - 1), gx = min(max(x0 + tx, 0), W - 1);
-        v[it] = src[(size_t)gy * pitch + gx];
+        vr[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gx];
     }
 #pragma unroll
-    for (unsigned it = 0; it < NL; it++) {
+    for (int it = 0; it < NM; it++) {
+        const int ty = w + 4 * it;
+        if (ty < LH) sL[ty * LSTRIDE + lane] = (TL)(float)vm[it];
+    }
+#pragma unroll
+    for (unsigned it = 0; it < NRL; it++) {
         const unsigned idx = threadIdx.x + 256u * it;
-        const int ty = (int)(idx / LWLOAD), tx = (int)(idx - (unsigned)ty * LWLOAD);
-        if (idx < N) sL[ty * LSTRIDE + tx] = (TL)(float)v[it];
+        const int ty = (int)(idx / REM), tx = 64 + (int)(idx - (unsigned)ty * REM);
+        if (idx < NR) sL[ty * LSTRIDE + tx] = (TL)(float)vr[it];
     }
 }
 
@@ -358,11 +378,24 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
-        const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
-        const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];            // GetGx: row below - row above
-        const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];          // GetGy: right - left
-        sG[idx] = (f2){gxv, gyv};
+    {
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
+            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)                                       // columns [0,64): wave = row
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {                           // the 10 right-hand columns
+            const unsigned idx = threadIdx.x + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
     }
     __syncthreads();
 
@@ -603,28 +636,44 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    {   // linear sweep, every lane busy; all LR and HR loads of a thread in flight before the first LDS write
-        constexpr unsigned N = LH * LW, NL = (N + 255u) / 256u;
-        TOut lv[NL];
-        float hv[NL];
-        bool inz[NL];
+    {   // wave w sweeps columns [0,64) of tile rows w, w+4, ...; the two right-hand halo columns go to the first 36 threads.
+        // All LR and HR loads of a thread are in flight before the first LDS write.
+        constexpr int NM = (LH + 3) / 4, REM = LW - 64;
+        static_assert(LH * REM <= 256, "halo columns fit one sweep");
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+        const int gxm = min(max(c0 - 1 + lane, 0), P.W - 1);
+        const bool inxm = gxm >= kMargin && gxm < P.c_final;
+        TOut lv[NM + 1];
+        float hv[NM + 1];
+        bool inz[NM + 1];
 #pragma unroll
-        for (unsigned it = 0; it < NL; it++) {
-            const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
-            const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-            const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-            lv[it] = lr[(size_t)gy * P.lr_pitch + gx];
-            inz[it] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
-            hv[it] = inz[it] ? hr[(size_t)gy * P.hr_pitch + gx] : 0.0f;
+        for (int it = 0; it < NM; it++) {
+            const int gy = min(max(r0 - 1 + min(wu + 4 * it, LH - 1), 0), P.H - 1);
+            lv[it] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gxm];
+            inz[it] = inxm && gy >= kMargin && gy < P.H - kMargin;
+            hv[it] = inz[it] ? hr[(unsigned)gy * (unsigned)P.hr_pitch + (unsigned)gxm] : 0.0f;
+        }
+        const int rty = min((int)(threadIdx.x / REM), LH - 1), rtx = 64 + (int)(threadIdx.x % REM);
+        {
+            const int gy = min(max(r0 - 1 + rty, 0), P.H - 1), gx = min(max(c0 - 1 + rtx, 0), P.W - 1);
+            lv[NM] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gx];
+            inz[NM] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
+            hv[NM] = inz[NM] ? hr[(unsigned)gy * (unsigned)P.hr_pitch + (unsigned)gx] : 0.0f;
         }
 #pragma unroll
-        for (unsigned it = 0; it < NL; it++) {
-            const unsigned idx = threadIdx.x + 256u * it;
+        for (int it = 0; it < NM; it++) {
+            const int ty = wu + 4 * it;
             const float L = (float)lv[it];
-            if (idx < N) {
-                sL[idx] = L;
-                sH[idx] = inz[it] ? hv[it] : L;                                     // HR := LR outside the filtered zone
+            if (ty < LH) {
+                sL[ty * LW + lane] = L;
+                sH[ty * LW + lane] = inz[it] ? hv[it] : L;                          // HR := LR outside the filtered zone
             }
+        }
+        if (threadIdx.x < LH * REM) {
+            const float L = (float)lv[NM];
+            sL[rty * LW + rtx] = L;
+            sH[rty * LW + rtx] = inz[NM] ? hv[NM] : L;
         }
     }
     __syncthreads();
