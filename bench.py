@@ -186,9 +186,8 @@ def main():
         step()
     fence()
     timing = not args.no_kernel_timing
-    if timing:
-        for d in lanes:
-            d.timing_enable(True)
+    if timing:                       # HIP events around every kernel of ONE lane (a third of the launches at 3 lanes):
+        lanes[0].timing_enable(True)  # enough launches for the average, a third of the event traffic in the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -199,11 +198,9 @@ def main():
     # per-kernel event timings (rank 0's lanes)
     kern = {}
     if timing:
-        for d in lanes:
-            for k, v in d.timing_read().items():
-                e = kern.setdefault(k, {"total_ms": 0.0, "count": 0})
-                e["total_ms"] += v["total_ms"]; e["count"] += v["count"]
-            d.timing_enable(False)
+        for k, v in lanes[0].timing_read().items():
+            kern[k] = {"total_ms": v["total_ms"], "count": v["count"]}
+        lanes[0].timing_enable(False)
 
     # isolated per-kernel durations: the same frames on ONE lane after the timed region (no other kernel
     # shares the chip), so a launch's duration is its own -- the overlapped average above is not

@@ -593,7 +593,10 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
                 const float v = tree16(acc);
                 if (v > P.lo && v < P.hi) res = v;
             }
-            if (s == l) keep = res;                             // lane (g,l) keeps pixel column 4l+g
+            {   // lane (g,l) keeps pixel column 4l+g: lanes with l == s, as a scalar mask (one VALU select, no compare)
+                const unsigned long long km = 0x0001000100010001ull << s;
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(km));
+            }
         }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
