@@ -275,6 +275,29 @@ __device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab, bool& ra
     return __uint_as_float(z);
 }
 
+// RCPPS(RSQRTPS(v)), branch-free (the composition of x86dev::rsqrt_legacy and x86dev::rcp_legacy):
+//   +normal: y = RSQRTPS(v) has exponent 126-half and the 12-bit mantissa code q = lut[2048 + 1024p + (m>>13)];
+//            RCPPS(y) looks up y's top 11 mantissa bits (= q>>1): exponent 253-(126-half) = (E+127)>>1, mantissa lut[q>>1]<<11;
+//   +-0 and +-denormal (DAZ) -> RSQRTPS = +-inf -> RCPPS = +-0;   -normal, -inf -> QNaN indefinite;
+//   +inf -> RSQRTPS = +0 -> RCPPS = +inf;   NaN -> quieted NaN.
+__device__ __forceinline__ float sqrt_legacy_fast(float v, const uint16_t* lut)
+{
+    const uint32_t x = __float_as_uint(v);
+    const uint32_t q = lut[2048u + (((x >> 13) & 2047u) ^ 1024u)];          // [p = ~E&1][m>>13]: bits 23..13, bit 23 inverted
+    const uint32_t r = lut[q >> 1];
+    const uint32_t ez = ((x + 0x3f800000u) >> 1) & 0x7f800000u;             // biased exponent (E+127)>>1 of the root
+    uint32_t z = ez | (r << 11);
+    const bool normal = __builtin_amdgcn_classf(v, 0x100);
+    const bool tiny = __builtin_amdgcn_classf(v, 0x0f0);                    // +-0, +-denormal
+    const bool negative = __builtin_amdgcn_classf(v, 0x00c);                // -inf, -normal
+    const bool nan = __builtin_amdgcn_classf(v, 0x003);
+    uint32_t sp = nan ? (x | 0x00400000u) : x;                              // NaN quieted; +inf stays +inf
+    sp = negative ? 0xffc00000u : sp;
+    sp = tiny ? (x & 0x80000000u) : sp;
+    z = normal ? z : sp;
+    return __uint_as_float(z);
+}
+
 // Hash thresholds, passed BY VALUE (SGPRs): taking PassParams by reference in an out-of-line function would
 // force the whole struct into scratch memory.
 struct HashQ { float qangle, qs0, qs1, qc0, qc1; const uint16_t* lut; };
@@ -284,7 +307,7 @@ struct HashQ { float qangle, qs0, qs1, qc0, qc1; const uint16_t* lut; };
 template <int MODE>
 __device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut, bool& rare)
 {
-    if (MODE == 1) return x86dev::rcp_legacy(x86dev::rsqrt_legacy(v, lut + 2048), lut);
+    if (MODE == 1) return sqrt_legacy_fast(v, lut);
     if (MODE == 2) return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
     return sqrt14_fast(v, tab, rare);
 }
@@ -358,7 +381,9 @@ __device__ __attribute__((noinline)) int hash_px_legacy(float a, float b, float 
 // ------------------------------------------------------------------------------------------------
 __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
-template <int R, typename T>
+// AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
+// LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
+template <int R, typename T, bool AVX2ALL>
 __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassParams P, GaussW gw,
                                                   uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
 {
@@ -367,14 +392,20 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
     constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
     __shared__ float sL[LH * LW];
     __shared__ f2 sG[GH * GW_];
-    __shared__ uint2 sTab[128];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
 
-    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    if constexpr (AVX2ALL) {
+        const uint2* src = reinterpret_cast<const uint2*>(P.lut_legacy);           // 4096 x u16 = 1024 x 8 B
+        for (int i = threadIdx.x; i < 1024; i += 256) reinterpret_cast<uint2*>(sLut)[i] = src[i];
+    } else {
+        if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    }
     stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
@@ -454,6 +485,22 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
         ad[j] = (holdAD[j] + curAD[j]) + t1AD[j];            // (Gb+Gc) + (Ga+Gd)
         bb[j] = (holdB[j] + curB[j]) + t1B[j];
     }
+    if constexpr (AVX2ALL) {
+        const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, sLut};
+        const bool inB = c >= P.b_begin && c < P.b_end;
+        unsigned h1[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            bool unused = false;
+            h1[j] = (unsigned)hash_px_impl<1>(ad[j].x, bb[j], ad[j].y, HQ, sTab, unused);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int r = r0 + w * R + j;
+            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)(inB ? h1[j] : 0xFFu);
+        }
+        return;
+    }
     // AVX-512 flavour for every pixel of the lane as straight-line code (independent chains interleave);
     // the rare cases -- generic approximation-instruction inputs, AVX2 flavour of the tail columns -- follow.
     const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
@@ -472,12 +519,12 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
         if (r < P.H - kMargin && c < P.c_final) {
             unsigned h = h1[j];
             if (rare[j]) h = (unsigned)hash_px_generic(ad[j].x, bb[j], ad[j].y, HQ, sTab);
-            if (inB) {                                       // AVX2 mode, or the tail columns of AVX-512 mode
+            if (inB) {                                       // the tail columns of AVX-512 mode
                 const unsigned hB = (unsigned)hash_px_legacy(ad[j].x, bb[j], ad[j].y, HQ, sTab);
                 if (inA) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;   // re-hashed tail column
                 else h = hB;
             }
-            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)(inA || inB ? h : 0xFFu);
+            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)(inA || inB ? h : 0xFFu);
         }
     }
 }
@@ -974,7 +1021,10 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         constexpr int R = 4;        // rows per lane: 3..6 measure the same within noise, 8 is slower (occupancy)
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         timer_begin(c, "k_hash", s, slot);
-        hipLaunchKernelGGL((k_hash<R, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+        if (P.a_end > P.a_begin)
+            hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+        else                                                // asm=avx2: no 16-wide chunks at all
+            hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
         timer_end(c, s, slot);
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         timer_begin(c, "k_filter", s, slot);
