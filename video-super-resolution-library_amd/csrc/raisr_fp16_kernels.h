@@ -268,18 +268,20 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
     for (int row = 0; row < 4; row++) {
         const int prow = 4 * w + row;
         const int r = r0 + prow;
-        hf keep = (hf)0.0f;
+        unsigned keepb = 0u;                                               // binary16 bits of the kept pixel
+        // pixel type of column c = c0 + 4s + g (c0 even): row part ((r-5)&1)*2, column part (c-5)&1 = (g+1)&1
+        const unsigned t = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((g + 1) & 1)) : 0u;
+        const uint32_t* frow = Q.bank16 + (t * 64u + (unsigned)l);
+        const unsigned bank_stride = (unsigned)P.pixel_types * 64u;        // half2 words per hash bucket
 #pragma unroll 4
         for (int s = 0; s < 16; s++) {
             const int pcol = 4 * s + g;
-            const int c = c0 + pcol;
             const unsigned hA = sH[prow * TW + pcol];
             const int base = prow * LW + pcol;
             const hf center = sL[base + 5 * LW + 5];
-            const int t = (P.pixel_types == 4) ? (((r - 5) & 1) * 2 + ((c - 5) & 1)) : 0;
             hf res = center;
             if (hA != 0xFFu) {
-                const uint32_t* f = Q.bank16 + ((size_t)(hA * P.pixel_types + t) * 64 + l);
+                const uint32_t* f = frow + __umul24(hA, bank_stride);
                 hf2 acc = (hf2){sL[base + off0[0]], sL[base + off1[0]]} * __builtin_bit_cast(hf2, f[0]);
 #pragma unroll
                 for (int ch = 1; ch < 4; ch++)
@@ -291,10 +293,14 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
                 v = v + row_ror_h<0x121>(v);                // s0 + s1
                 if (v > lo && v < hi) res = v;
             }
-            if (s == l) keep = res;
+            {   // lanes with l == s keep this step's pixel: scalar lane mask, one VALU select
+                const unsigned long long km = 0x0001000100010001ull << s;
+                const unsigned rb = h_u(res);
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keepb) : "v"(rb), "s"(km));
+            }
         }
         const int c = c0 + 4 * l + g;
-        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = h_u(keep);
+        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = (uint16_t)keepb;
     }
 }
 
