@@ -113,7 +113,42 @@ int raisr_hip_process_host(raisr_hip_ctx *ctx,
                            const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
                            const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
                            int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h);
-int raisr_hip_synchronize(raisr_hip_ctx *ctx);
+int raisr_hip_synchronize(raisr_hip_ctx *ctx);   /* waits for everything the context has enqueued (Y and chroma lanes) */
+
+/* Horizontal bands ----------------------------------------------------------------------------
+ * A frame can be cut into horizontal bands that are processed as INDEPENDENT sub-frames, each by its own
+ * context (own stream, or own GPU): a band's sub-frame carries enough extra input rows above and below its
+ * kept rows that every kept output row equals the whole-frame result bit for bit -- no halo exchange, no
+ * ordering between bands.  This is the GPU counterpart of the reference's thread bands (RNLSetRes zone
+ * arithmetic, Library/Raisr.cpp:1738-1779; the reference pads bands by gResizeExpand/gHashingExpand rows for
+ * the same reason), used (a) by RNLProcess to overlap one band's PCIe transfers with another band's kernels
+ * and (b) to split one frame over several GPUs (latency mode).
+ *   passes = 0 plans a plane that only goes through the cheap upscale (chroma).
+ * Returns the number of bands planned (1..nbands; fewer when the plane is too small or the ratio cannot be
+ * aligned), or a negative RAISR_HIP_E* code. */
+typedef struct raisr_hip_band {
+    int in_row_begin, in_row_count;      /* input rows of the sub-frame (kept rows + padding), frame coordinates   */
+    int out_row_begin, out_row_count;    /* output rows the sub-frame produces, frame coordinates                  */
+    int keep_begin, keep_count;          /* output rows of the sub-frame that are valid and owned by this band    */
+} raisr_hip_band;
+int raisr_hip_plan_bands(int in_height, int out_height, int passes, int nbands, raisr_hip_band *bands);
+
+/* raisr_hip_process_host without the final wait and with a row window on the download: only rows
+ * [y_skip, y_skip + y_keep) of the Y output (and [c_skip, c_skip + c_keep) of each chroma output) are copied
+ * back, to out_y / out_u / out_v, which point at the FIRST KEPT ROW in the caller's planes.  rows == NULL keeps
+ * everything.  Finish with raisr_hip_synchronize(). */
+typedef struct raisr_hip_rows {
+    int y_skip, y_keep, c_skip, c_keep;
+    int stage;      /* 0: upload, kernels and download; 1: upload + kernels only; 2: download only.  Downloads into
+                     * pageable memory block the calling thread until the band's kernels are done, so a caller with
+                     * several bands issues stage 1 for all of them before the first stage 2. */
+} raisr_hip_rows;
+int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
+                                 const void *in_y, size_t in_y_pitch, void *out_y, size_t out_y_pitch,
+                                 const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
+                                 const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
+                                 int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h,
+                                 const raisr_hip_rows *rows);
 
 /* Introspection for tests / profiling ---------------------------------------------------------
  * Copies the last frame's per-pixel hash plane (u8: bucket 0..215 of the first hash, stale outside the

@@ -13,6 +13,7 @@
 // State is one process-global instance, as in the reference (Library/Raisr_globals.h:140-203).
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -43,7 +44,12 @@ struct State {
     int hashVariant = RAISR_HIP_HASH_AVX512;
     unsigned qAngle = 0, qStrength = 0, qCoherence = 0, patchSize = 0;
     PassModel model[2];
-    raisr_hip_ctx *ctx = nullptr;
+    raisr_hip_ctx *ctx = nullptr;                 // band 0 (the whole frame when the frame is not cut)
+    // Horizontal bands (include/raisr_hip.h "Horizontal bands"): band k runs on its own context/stream so that
+    // its uploads and downloads overlap the other bands' kernels inside one synchronous RNLProcess call.
+    std::vector<raisr_hip_ctx *> extra;           // contexts of bands 1..K-1
+    std::vector<raisr_hip_band> yBands, cBands;   // luma / chroma plans (same count; cBands empty = chroma on band 0)
+    int chromaInH = 0, chromaOutH = 0;
 } G;
 
 // ---- config / trained-data parsing -------------------------------------------------------------
@@ -156,10 +162,41 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
     return RNLErrorNone;
 }
 
+void dropExtraBands()
+{
+    for (raisr_hip_ctx *c : G.extra) raisr_hip_destroy(c);
+    G.extra.clear(); G.yBands.clear(); G.cBands.clear();
+}
+
 void dropContext()
 {
+    dropExtraBands();
     if (G.ctx) { raisr_hip_destroy(G.ctx); G.ctx = nullptr; }
     G.resSet = false;
+}
+
+int uploadModels(raisr_hip_ctx *ctx)
+{
+    for (unsigned p = 0; p < G.passes; p++) {
+        const PassModel &M = G.model[p];
+        const int rc = raisr_hip_set_model(ctx, (int)p, M.bank.data(), (int)M.hashkeys, (int)M.pixelTypes, M.qstr.data(), M.qcoh.data(), (int)G.qAngle);
+        if (rc != RAISR_HIP_OK) return rc;
+    }
+    return RAISR_HIP_OK;
+}
+
+// How many bands RNLProcess cuts a frame into: RAISR_HIP_BANDS=n (default 1 = never cut).  Measured on
+// 1080p->4K yuv420p: the host path is bound by the plane copies themselves (0.54 ms/frame uncut; 0.52 ms with two
+// bands, slower with more: every band adds launches and padding rows), so cutting is left to callers that want it --
+// page-locked planes, or one band per GPU through the device layer.
+int wantedBands(int outHeight)
+{
+    if (const char *e = std::getenv("RAISR_HIP_BANDS")) {
+        const int n = std::atoi(e);
+        if (n >= 1) return n > 16 ? 16 : n;
+    }
+    (void)outHeight;
+    return 1;
 }
 
 }  // namespace
@@ -280,14 +317,11 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
         std::cout << "[RAISR ERROR] HIP backend unavailable: " << raisr_hip_last_error() << std::endl;
         return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : RNLErrorUndefined;
     }
-    for (unsigned p = 0; p < G.passes; p++) {
-        const PassModel &M = G.model[p];
-        rc = raisr_hip_set_model(G.ctx, (int)p, M.bank.data(), (int)M.hashkeys, (int)M.pixelTypes, M.qstr.data(), M.qcoh.data(), (int)G.qAngle);
-        if (rc != RAISR_HIP_OK) {
-            std::cout << "[RAISR ERROR] uploading model failed: " << raisr_hip_last_error() << std::endl;
-            dropContext();
-            return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : RNLErrorBadParameter;
-        }
+    rc = uploadModels(G.ctx);
+    if (rc != RAISR_HIP_OK) {
+        std::cout << "[RAISR ERROR] uploading model failed: " << raisr_hip_last_error() << std::endl;
+        dropContext();
+        return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : RNLErrorBadParameter;
     }
     G.inited = true;
     return RNLErrorNone;
@@ -296,7 +330,7 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
 RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *inCb,
                        VideoDataType *outY, VideoDataType *outCr, VideoDataType *outCb)
 {
-    (void)inCr; (void)inCb; (void)outCr; (void)outCb;
+    (void)inCb; (void)outCb;
     if (!G.inited || !G.ctx || !inY || !outY) return RNLErrorBadParameter;
     raisr_hip_config cfg{};
     cfg.in_width = (int)inY->width; cfg.in_height = (int)inY->height;
@@ -308,10 +342,43 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
     cfg.blending = RAISR_HIP_BLEND_COUNT;
     cfg.use_pixel_type = G.ratio == 2.0f ? 1 : 0;     // gUsePixelType, Raisr.cpp:1477-1480
     cfg.tie_rule = RAISR_HIP_TIE_HALF_UP;
-    const int rc = raisr_hip_configure(G.ctx, &cfg);
-    if (rc != RAISR_HIP_OK) {
+
+    // band plan: luma with the pass count's padding, chroma (cheap upscale only) with its own
+    dropExtraBands();
+    G.resSet = false;
+    const int want = wantedBands(cfg.out_height);
+    std::vector<raisr_hip_band> yb((size_t)want), cb((size_t)want);
+    int K = want > 1 ? raisr_hip_plan_bands(cfg.in_height, cfg.out_height, cfg.passes, want, yb.data()) : 1;
+    if (K < 1) K = 1;
+    G.chromaInH = inCr ? (int)inCr->height : 0; G.chromaOutH = outCr ? (int)outCr->height : 0;
+    bool chromaBanded = false;
+    if (K > 1 && G.chromaInH > 0 && G.chromaOutH > 0)
+        chromaBanded = raisr_hip_plan_bands(G.chromaInH, G.chromaOutH, 0, K, cb.data()) == K;
+
+    auto failed = [&](int rc) {
         std::cout << "[RAISR ERROR] set resolution failed: " << raisr_hip_last_error() << std::endl;
+        dropExtraBands();
         return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : RNLErrorBadParameter;
+    };
+    if (K > 1) {
+        for (int k = 0; k < K; k++) {
+            raisr_hip_ctx *ctx = G.ctx;
+            if (k > 0) {
+                ctx = nullptr;
+                int rc = raisr_hip_create(&ctx, G.device);
+                if (rc == RAISR_HIP_OK) { G.extra.push_back(ctx); rc = uploadModels(ctx); }
+                if (rc != RAISR_HIP_OK) return failed(rc);
+            }
+            raisr_hip_config sub = cfg;
+            sub.in_height = yb[(size_t)k].in_row_count; sub.out_height = yb[(size_t)k].out_row_count;
+            const int rc = raisr_hip_configure(ctx, &sub);
+            if (rc != RAISR_HIP_OK) return failed(rc);
+        }
+        G.yBands.assign(yb.begin(), yb.begin() + K);
+        if (chromaBanded) G.cBands.assign(cb.begin(), cb.begin() + K);
+    } else {
+        const int rc = raisr_hip_configure(G.ctx, &cfg);
+        if (rc != RAISR_HIP_OK) return failed(rc);
     }
     G.resSet = true;
     return RNLErrorNone;
@@ -325,16 +392,56 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
     if (!inCb || !inCb->pData || !outCb || !outCb->pData) return RNLErrorBadParameter;
     if (!G.inited || !G.resSet || !G.ctx) return RNLErrorBadParameter;
     if (blendingMode != CountOfBitsChanged && blendingMode != Randomness) return RNLErrorBadParameter;
-    if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
-    const int rc = raisr_hip_process_host(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
-                                          inCr->pData, inCr->step, outCr->pData, outCr->step,
-                                          inCb->pData, inCb->step, outCb->pData, outCb->step,
-                                          (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height);
-    if (rc != RAISR_HIP_OK) {
+    auto failed = [&]() {
         std::cout << "[RAISR ERROR] process failed: " << raisr_hip_last_error() << std::endl;
         return RNLErrorUndefined;
+    };
+    const size_t K = G.yBands.size();
+    if (K <= 1) {
+        if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
+        const int rc = raisr_hip_process_host(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
+                                              inCr->pData, inCr->step, outCr->pData, outCr->step,
+                                              inCb->pData, inCb->step, outCb->pData, outCb->step,
+                                              (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height);
+        return rc != RAISR_HIP_OK ? failed() : RNLErrorNone;
     }
-    return RNLErrorNone;
+    // the planes must still have the geometry the bands were planned for
+    if ((int)inCr->height != G.chromaInH || (int)outCr->height != G.chromaOutH) return RNLErrorBadParameter;
+    // stage 1 (upload + kernels) for every band first, then the downloads: a download into pageable memory blocks
+    // this thread until its band's kernels are done, and meanwhile the later bands' kernels keep the GPU busy
+    int rc = RAISR_HIP_OK;
+    for (int stage = 1; stage <= 2 && rc == RAISR_HIP_OK; stage++) {
+        for (size_t k = 0; k < K && rc == RAISR_HIP_OK; k++) {
+            raisr_hip_ctx *ctx = k == 0 ? G.ctx : G.extra[k - 1];
+            if (stage == 1 && raisr_hip_set_blending(ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
+            const raisr_hip_band &y = G.yBands[k];
+            raisr_hip_rows rows{y.keep_begin - y.out_row_begin, y.keep_count, 0, 0, stage};
+            const unsigned char *iu = nullptr, *iv = nullptr;
+            unsigned char *ou = nullptr, *ov = nullptr;
+            int cih = 0, coh = 0;
+            if (!G.cBands.empty()) {
+                const raisr_hip_band &c = G.cBands[k];
+                rows.c_skip = c.keep_begin - c.out_row_begin; rows.c_keep = c.keep_count;
+                iu = inCr->pData + (size_t)c.in_row_begin * inCr->step; iv = inCb->pData + (size_t)c.in_row_begin * inCb->step;
+                ou = outCr->pData + (size_t)c.keep_begin * outCr->step; ov = outCb->pData + (size_t)c.keep_begin * outCb->step;
+                cih = c.in_row_count; coh = c.out_row_count;
+            } else if (k == 0) {            // chroma too small to cut: band 0 does the whole planes
+                rows.c_skip = 0; rows.c_keep = (int)outCr->height;
+                iu = inCr->pData; iv = inCb->pData; ou = outCr->pData; ov = outCb->pData;
+                cih = (int)inCr->height; coh = (int)outCr->height;
+            }
+            rc = raisr_hip_process_host_async(ctx, inY->pData + (size_t)y.in_row_begin * inY->step, inY->step,
+                                              outY->pData + (size_t)y.keep_begin * outY->step, outY->step,
+                                              iu, inCr->step, ou, outCr->step, iv, inCb->step, ov, outCb->step,
+                                              (int)inCr->width, cih, (int)outCr->width, coh, &rows);
+        }
+    }
+    // always drain every band, also after an error, so that no transfer into the caller's planes is left in flight
+    for (size_t k = 0; k < K; k++) {
+        const int r2 = raisr_hip_synchronize(k == 0 ? G.ctx : G.extra[k - 1]);
+        if (rc == RAISR_HIP_OK) rc = r2;
+    }
+    return rc != RAISR_HIP_OK ? failed() : RNLErrorNone;
 }
 
 RNLERRORTYPE RNLSetOpenCLContext(void *context, void *deviceID, int platformIndex, int deviceIndex)

@@ -1384,7 +1384,47 @@ int raisr_hip_synchronize(raisr_hip_ctx* c)
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
     return RAISR_HIP_OK;
+}
+
+// Band plan: see include/raisr_hip.h.  Validity of the kept rows (output rows, counted from an ARTIFICIAL
+// sub-frame border; a real frame border needs no padding):
+//   cheap upscale only      the first/last output rows interpolate against a replicated input row      -> 1 input row
+//   one pass                LR row 0 is wrong (replicated input row); HR row q reads LR rows q-6..q+6 and is
+//                           unfiltered for q < 6; the blend of row r reads HR rows r-1..r+1           -> r >= 8 output rows
+//   two passes, mode 1      pass 2 reads pass-1 rows r-7..r+7, which must be valid themselves          -> r >= 16
+//   two passes, mode 2      pass 1 (input size) valid from input row 7, upscaled, then as one pass     -> 12 (2x) / 14 (1.5x) input rows
+// The padding below (6 input rows for one pass at 2x, 16 for two, 2 for chroma) covers these with margin; it is
+// a multiple of the alignment unit so that band starts keep the upscale phase and the pixel-type parity.
+int raisr_hip_plan_bands(int in_height, int out_height, int passes, int nbands, raisr_hip_band* bands)
+{
+    if (in_height <= 0 || out_height <= 0 || passes < 0 || passes > 2 || nbands < 1 || !bands) return fail(RAISR_HIP_EINVAL, "bad band request");
+    const int g = gcd_int(in_height, out_height);
+    const int num = out_height / g, den = in_height / g;
+    const int align = (den % 2 == 0) ? den : 2 * den;         // band starts: whole upscale periods, even rows
+    // input rows of padding at an artificial border: the validity distances above, converted to input rows, plus margin
+    const int out8 = (8 * den + num - 1) / num;                // 8 output rows in input rows, rounded up
+    int pad = passes == 0 ? 2 : (passes == 1 ? out8 + 2 : 9 + out8 + 3);
+    pad = (pad + align - 1) / align * align;
+    int K = nbands;
+    const int min_rows = 2 * pad + 2 * align;                  // a band keeps at least this many input rows
+    if (align > 32 || in_height / min_rows < 2) K = 1;
+    else if (K > in_height / min_rows) K = in_height / min_rows;
+    for (int k = 0; k < K; k++) {
+        const int s0 = k == 0 ? 0 : (int)((long long)in_height * k / K) / align * align;
+        const int s1 = k == K - 1 ? in_height : (int)((long long)in_height * (k + 1) / K) / align * align;
+        raisr_hip_band& b = bands[k];
+        b.in_row_begin = s0 - pad > 0 ? s0 - pad : 0;
+        const int in_end = s1 + pad < in_height ? s1 + pad : in_height;
+        b.in_row_count = in_end - b.in_row_begin;
+        b.out_row_begin = (int)((long long)b.in_row_begin * num / den);
+        const int out_end = in_end == in_height ? out_height : (int)((long long)in_end * num / den);
+        b.out_row_count = out_end - b.out_row_begin;
+        b.keep_begin = (int)((long long)s0 * num / den);
+        b.keep_count = (s1 == in_height ? out_height : (int)((long long)s1 * num / den)) - b.keep_begin;
+    }
+    return K;
 }
 
 int raisr_hip_process_host(raisr_hip_ctx* c,
@@ -1393,12 +1433,31 @@ int raisr_hip_process_host(raisr_hip_ctx* c,
                            const void* in_v, size_t in_v_pitch, void* out_v, size_t out_v_pitch,
                            int cin_w, int cin_h, int cout_w, int cout_h)
 {
+    const int rc = raisr_hip_process_host_async(c, in_y, in_y_pitch, out_y, out_y_pitch, in_u, in_u_pitch, out_u, out_u_pitch,
+                                                in_v, in_v_pitch, out_v, out_v_pitch, cin_w, cin_h, cout_w, cout_h, nullptr);
+    if (rc) return rc;
+    return raisr_hip_synchronize(c);
+}
+
+int raisr_hip_process_host_async(raisr_hip_ctx* c,
+                                 const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
+                                 const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
+                                 const void* in_v, size_t in_v_pitch, void* out_v, size_t out_v_pitch,
+                                 int cin_w, int cin_h, int cout_w, int cout_h, const raisr_hip_rows* rows)
+{
     if (!c || !in_y || !out_y) return fail(RAISR_HIP_EINVAL, "null plane");
     if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
     HIP_TRY(hipSetDevice(c->device));
     const raisr_hip_config& g = c->cfg;
     const int bps = g.bits == 8 ? 1 : 2;
     const bool chroma = in_u && out_u && in_v && out_v && cin_w > 0 && cin_h > 0 && cout_w > 0 && cout_h > 0;
+    const int y_skip = rows ? rows->y_skip : 0, y_keep = rows ? rows->y_keep : g.out_height;
+    const int c_skip = rows ? rows->c_skip : 0, c_keep = rows ? rows->c_keep : cout_h;
+    const int stage = rows ? rows->stage : 0;
+    if (stage < 0 || stage > 2) return fail(RAISR_HIP_EINVAL, "bad stage");
+    const bool do_up = stage != 2, do_down = stage != 1;
+    if (y_skip < 0 || y_keep < 0 || y_skip + y_keep > g.out_height || (chroma && (c_skip < 0 || c_keep < 0 || c_skip + c_keep > cout_h)))
+        return fail(RAISR_HIP_EINVAL, "row window outside the plane");
     // tightly packed device staging: [inY][inU][inV][outY][outU][outV]
     const size_t iy = (size_t)g.in_width * g.in_height * bps, oy = (size_t)g.out_width * g.out_height * bps;
     const size_t ic = chroma ? (size_t)cin_w * cin_h * bps : 0, oc = chroma ? (size_t)cout_w * cout_h * bps : 0;
@@ -1415,24 +1474,30 @@ int raisr_hip_process_host(raisr_hip_ctx* c,
     hipStream_t s = c->stream, s2 = c->stream2;
     // Y: upload, RAISR passes, download on the context stream; chroma (plain cheap upscale, Raisr.cpp:1373-1388)
     // runs on a second stream so its PCIe transfers overlap the Y kernels.
-    HIP_TRY(hipMemcpy2DAsync(d, (size_t)g.in_width * bps, in_y, in_y_pitch, (size_t)g.in_width * bps, g.in_height, hipMemcpyHostToDevice, s));
-    if (c->blending == RAISR_HIP_BLEND_RANDOMNESS)   // pixels the reference leaves untouched keep the caller's bytes
-        HIP_TRY(hipMemcpy2DAsync(d + off_oy, (size_t)g.out_width * bps, out_y, out_y_pitch, (size_t)g.out_width * bps, g.out_height, hipMemcpyHostToDevice, s));
-    int rc = raisr_hip_process_y_device(c, d, (size_t)g.in_width * bps, d + off_oy, (size_t)g.out_width * bps, s);
-    if (rc) return rc;
-    if (chroma) {
-        HIP_TRY(hipMemcpy2DAsync(d + off_iu, (size_t)cin_w * bps, in_u, in_u_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s2));
-        HIP_TRY(hipMemcpy2DAsync(d + off_iv, (size_t)cin_w * bps, in_v, in_v_pitch, (size_t)cin_w * bps, cin_h, hipMemcpyHostToDevice, s2));
-        rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, (size_t)cin_w * bps, d + off_ou, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s2);
+    const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
+    const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
+    if (do_up) {
+        HIP_TRY(hipMemcpy2DAsync(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
+        if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
+            HIP_TRY(hipMemcpy2DAsync(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
+        int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
         if (rc) return rc;
-        rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, (size_t)cin_w * bps, d + off_ov, cout_w, cout_h, (size_t)cout_w * bps, g.bits, s2);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s2));
-        HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov, (size_t)cout_w * bps, (size_t)cout_w * bps, cout_h, hipMemcpyDeviceToHost, s2));
+        if (chroma) {
+            HIP_TRY(hipMemcpy2DAsync(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(hipMemcpy2DAsync(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+            rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+        }
     }
-    HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy, (size_t)g.out_width * bps, (size_t)g.out_width * bps, g.out_height, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (chroma) HIP_TRY(hipStreamSynchronize(s2));
+    if (do_down) {
+        if (chroma && c_keep > 0) {
+            HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+        }
+        if (y_keep > 0) HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
+    }
     return RAISR_HIP_OK;
 }
 

@@ -40,6 +40,15 @@ class VideoDataType(ctypes.Structure):
                 ("step", ctypes.c_uint), ("bitShift", ctypes.c_uint)]
 
 
+class RaisrHipBand(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("in_row_begin", "in_row_count", "out_row_begin", "out_row_count",
+                                            "keep_begin", "keep_count")]
+
+
+class RaisrHipRows(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("y_skip", "y_keep", "c_skip", "c_keep", "stage")]
+
+
 class RaisrHipConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "in_width", "in_height", "out_width", "out_height", "bits", "clamp_lo", "clamp_hi", "passes",
@@ -92,6 +101,7 @@ def lib():
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
         L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -126,6 +136,15 @@ def clamp_range(bits, full_range):
 # ----------------------------------------------------------------------------------------------
 # Reference plugin API (host planes)
 # ----------------------------------------------------------------------------------------------
+def plan_bands(in_height, out_height, passes, nbands):
+    """Band plan of include/raisr_hip.h (pure host arithmetic, no GPU): list of dicts, one per band."""
+    arr = (RaisrHipBand * max(1, nbands))()
+    k = lib().raisr_hip_plan_bands(in_height, out_height, passes, nbands, arr)
+    if k < 0:
+        raise ValueError(last_error())
+    return [{n: getattr(arr[i], n) for n, _ in RaisrHipBand._fields_} for i in range(k)]
+
+
 def RNLHandler_Init(model_path, ratio, bit_depth=8, range_type=VideoRange, thread_count=20, asm_type=AVX512,
                     passes=1, two_pass_mode=1):
     return lib().RNLHandler_Init(os.fsencode(model_path), ratio, bit_depth, range_type, thread_count, asm_type,

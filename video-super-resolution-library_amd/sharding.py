@@ -1,7 +1,8 @@
 """Multi-GPU plumbing for the frame-sharded RAISR job (one process per GPU).
 
 Frames are independent (RNLProcess is a pure per-frame function, reference Library/Raisr.cpp:1294),
-so frame i of a stream goes to rank i mod world and no rank ever exchanges pixels.  The only
+so frame i of a stream goes to rank i mod world and no rank ever exchanges pixels.  (For latency rather than
+throughput a single frame can also be cut into horizontal bands, one per rank: band_for_rank.)  The only
 collective is one broadcast of the packed filter-bank blob(s) from the rank that read the model
 files: RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.
 """
@@ -11,6 +12,17 @@ import numpy as np
 def frames_for_rank(n_frames, rank, world):
     """Indices of the frames rank `rank` owns under round-robin sharding."""
     return list(range(rank, n_frames, world))
+
+
+def band_for_rank(in_height, out_height, passes, rank, world):
+    """Latency mode: ONE frame split over `world` GPUs.  Returns rank `rank`'s band of the plan of
+    raisr_hip_plan_bands (dict with in_row_begin/in_row_count, out_row_begin/out_row_count, keep_begin/keep_count), or
+    None when the frame is too small to give this rank a band.  Bands are independent sub-frames: the rank uploads
+    input rows [in_row_begin, +in_row_count), runs the ordinary pipeline configured for that sub-frame and owns output
+    rows [keep_begin, +keep_count) -- no pixels are exchanged between ranks (the padding rows are recomputed instead)."""
+    import raisr_hip as R
+    bands = R.plan_bands(in_height, out_height, passes, world)
+    return bands[rank] if rank < len(bands) else None
 
 
 def broadcast_model_blob(blob, nbytes, device, dist=None, src=0):
