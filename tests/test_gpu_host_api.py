@@ -114,3 +114,27 @@ def test_device_resident_yuv_frame_matches_host_path():
     dev.close()
     assert np.array_equal(doy.cpu().numpy(), oy) and np.array_equal(dou.cpu().numpy(), ou) and np.array_equal(dov.cpu().numpy(), ov)
 
+
+
+@pytest.mark.parametrize("layout,cw_div,ch_div", [("yuv422p", 2, 1), ("yuv444p", 1, 1)])
+def test_rnlhandler_chroma_layouts(layout, cw_div, ch_div):
+    """vf_raisr also accepts 4:2:2 and 4:4:4 (ffmpeg/vf_raisr.c:158-162): the chroma planes simply have other sizes;
+    each goes through the cheap upscale at its own size."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h = 96, 64
+    y = synth.natural_y(w, h, 8, seed=12)
+    u = synth.random_y(w // cw_div, h // ch_div, 8, seed=3)
+    v = synth.random_y(w // cw_div, h // ch_div, 8, seed=4)
+    oy = np.zeros((2 * h, 2 * w), np.uint8)
+    ou = np.zeros((2 * h // ch_div, 2 * w // cw_div), np.uint8); ov = np.zeros_like(ou)
+    assert R.RNLHandler_Init(folder("filters_2x/filters_highres"), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        assert R.RNLHandler_SetRes((y, u, v), (oy, ou, ov)) == 0
+        assert R.RNLHandler_Process((y, u, v), (oy, ou, ov), R.CountOfBitsChanged) == 0
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+    assert np.array_equal(oy, oracle_y(y, ("x", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False)))
+    assert np.array_equal(ou, O.resize(u, ou.shape[1], ou.shape[0]).astype(np.uint8))
+    assert np.array_equal(ov, O.resize(v, ov.shape[1], ov.shape[0]).astype(np.uint8))
