@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=24)
-    ap.add_argument("--lanes", type=int, default=3, help="frames in flight per GPU (one context+stream each); 3 measured best")
+    ap.add_argument("--lanes", type=int, default=4, help="frames in flight per GPU (one context+stream each); 2-4 measure within 2 %%")
     ap.add_argument("--passes", type=int, default=0, help="override the config's pass count (1 or 2)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration; the bench line is C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -45,8 +45,10 @@ HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.
 VALU_FP32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md "Peak FP32 (vector)": 4 SIMD-32 per CU, all-FMA.
 # (scripts/valu_rate_probe.hip sustains 911 G wave-inst/s = 116.6 TFLOP/s of v_fma_f32 on this power-limited part; the
 #  structure tensor's mix of 2 mul + 3 fma per tap can reach at most 1013/(2*605) = 84 % of an all-FMA peak.)
-# SURVEY.md s8d per-filtered-pixel FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add, hash ~60
+# SURVEY.md s8d per-filtered-pixel FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add, hash ~60,
+# filter 121 fma + 15 add
 HASH_FLOP_PER_PIXEL = 121 * (2 + 6) + 45 + 60
+FILTER_FLOP_PER_PIXEL = 121 * 2 + 15
 
 # BASELINE.json configs.  The bench line is C2 (configs[1]); the others are selectable for
 # profiling: (in_w, in_h, out_w, out_h, folder, bits, passes, mode, hash variant, description)
@@ -219,7 +221,8 @@ def main():
     if rank == 0:
         roofline = None
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
-        dom = "k_hash16" if CFG["asm"] == 5 else "k_hash"
+        # dominant kernel: the fused tensor/hash + filter kernel (fp32 paths), the hash kernel of the binary16 pipeline
+        dom = "k_hash16" if CFG["asm"] == 5 else ("k_hashfilter" if "k_hashfilter" in kern else "k_hash")
         if dom in kern and kern[dom]["count"]:
             # with two passes the kernel runs twice per frame: one launch still processes one frame-pass
             avg_s = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3
@@ -229,14 +232,15 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tpath) and CFG["name"] == "C2":
                 try:
-                    traffic = json.load(open(tpath)).get("k_hash_hbm_bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("dominant_kernel_hbm_bytes_per_launch") if tj.get("dominant_kernel") == dom else None
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                         "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": int(algo_per_launch),
                         "lanes_overlapped": args.lanes,
-                        "note": "path is fp32-VALU bound (~1 kFLOP per output pixel vs 1.25 compulsory bytes); "
+                        "note": "path is fp32-VALU bound (~1.3 kFLOP per output pixel vs 1.25 compulsory bytes); "
                                 "HBM fraction is reported as required, VALU utilisation is the binding figure (DESIGN.md)"}
             if dom in iso and iso[dom] > 0:
                 # the binding resource: fp32 VALU.  Filtered zone of one launch x the s8d FLOP model / isolated duration
@@ -247,9 +251,10 @@ def main():
                     px = ((c1 - 6) * (IN_H - 12) + zone_w * zone_h) / 2
                 else:
                     px = zone_w * zone_h
-                tflops = px * HASH_FLOP_PER_PIXEL / (iso[dom] * 1e-3) / 1e12
+                flop_px = HASH_FLOP_PER_PIXEL + (FILTER_FLOP_PER_PIXEL if dom == "k_hashfilter" else 0)
+                tflops = px * flop_px / (iso[dom] * 1e-3) / 1e12
                 roofline["valu"] = {"kernel": dom, "isolated_launch_ms": round(iso[dom], 4),
-                                    "flop_per_launch": int(px * HASH_FLOP_PER_PIXEL), "achieved": round(tflops, 2),
+                                    "flop_per_launch": int(px * flop_px), "achieved": round(tflops, 2),
                                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s (fp32 VALU)",
                                     "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4)}
         cpu = None

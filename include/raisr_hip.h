@@ -153,7 +153,10 @@ int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
 /* Introspection for tests / profiling ---------------------------------------------------------
  * Copies the last frame's per-pixel hash plane (u8: bucket 0..215 of the first hash, stale outside the
  * filtered zone) and HR plane (fp32; binary16 bit patterns in the low half-words in FP16 mode) of pass
- * `pass_index` to host buffers (either may be NULL). */
+ * `pass_index` to host buffers (either may be NULL).
+ * The hash plane is only materialised for frames processed after raisr_hip_debug_keep_stages(ctx, 1): the
+ * production kernel keeps the hashes on chip. */
+int raisr_hip_debug_keep_stages(raisr_hip_ctx *ctx, int on);
 int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash_out, float *hr_out);
 /* Hash bucket (0..215) of `n` host-side structure-tensor triples (a, b, d) x n with pass `pass_index`'s
  * thresholds, computed by the very device functions the hash kernel runs (fast path plus generic fall-back

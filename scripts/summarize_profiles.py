@@ -13,7 +13,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERN = ("k_hash16", "k_filter16", "k_blend16", "k_hash", "k_filter", "k_blend", "k_resize2x", "k_resize")
+KERN = ("k_hashfilter", "k_hash16", "k_filter16", "k_blend16", "k_hash", "k_filter", "k_blend", "k_resize2x", "k_resize")
 
 
 def short(name):
@@ -23,7 +23,7 @@ def short(name):
     return name[:60]
 
 
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --steps 20 --warmup 3` (1080p->4K 2x, highres, 1-pass, 3 lanes x 24 frames/step)", ""]
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --steps 20 --warmup 3` (1080p->4K 2x, highres, 1-pass, 4 lanes x 24 frames/step)", ""]
 f = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # newest run first
 if f:
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
@@ -55,20 +55,22 @@ if pmc:
     for k, v in pmc.items():
         lines.append(f"| {k} | " + " | ".join(f"{v.get(c, float('nan')):.4g}" for c in cols) + " |")
     lines += ["", "Units: SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves; FETCH_SIZE / WRITE_SIZE are KiB as reported.",
-              "Calibration (MI355X_MICROARCH.md asks for one per access pattern): the gfx950 half-count of FETCH_SIZE applies to wide",
-              "16-B/lane streams; these kernels load 1-4 B per lane.  Known byte counts: k_resize2x writes exactly one u16 LR plane",
-              "(16 588 800 B = 16 200 KiB == WRITE_SIZE); k_blend must fetch the LR (u16) and HR (f32) planes with an 18/16 x 66/64 tile",
-              "halo = 49.8 MB x 1.16 = 57.7 MB minimum vs FETCH_SIZE 62 980 KiB = 64.5 MB -- i.e. FETCH_SIZE is NOT halved for this",
-              "access pattern, so no x2 correction is applied below.", ""]
+              "Calibration on known byte counts of these kernels' own access patterns (MI355X_MICROARCH.md asks for one):",
+              "* WRITE_SIZE: k_resize2x writes exactly one u8 LR plane, 8 294 400 B = 8 100 KiB == WRITE_SIZE -> no correction.",
+              "* FETCH_SIZE: k_blend has to fetch the LR plane (u8, 8.29 MB) and the HR plane (f32, 33.18 MB) that the previous",
+              "  kernels wrote -- 41.5 MB per launch at the very least (the 4 MiB L2s cannot hold them; Infinity-Cache hits are",
+              "  counted) -- and FETCH_SIZE reports half of that: the gfx950 half-count (128-B requests tallied at 64 B) applies to",
+              "  these row-coalesced loads too, so FETCH_SIZE is doubled below, as the guide prescribes.", ""]
     traffic = {}
     for k, v in pmc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            traffic[k] = int((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+            traffic[k] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if traffic:
-        lines += ["## HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
-        json.dump({"k_hash_hbm_bytes_per_launch": traffic.get("k_hash"), "per_kernel": traffic,
-                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (FETCH_SIZE + WRITE_SIZE)*1024; "
-                             "no x2 FETCH correction: calibrated on k_resize2x/k_blend known byte counts (narrow per-lane loads), see the summary"},
+        lines += ["## HBM-side bytes per launch (2 * FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
+        dom = "k_hashfilter" if "k_hashfilter" in traffic else "k_hash"
+        json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel": traffic,
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--lanes 1); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
+                             "gfx950 FETCH_SIZE half-count confirmed on k_blend's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
                   open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

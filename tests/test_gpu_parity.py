@@ -31,6 +31,7 @@ def _gpu(y, case):
     dev.set_model_from_folder(folder(fold), bits, passes)
     dev.configure(w, h, ow, oh, bits=bits, full_range=full, passes=passes, mode=mode, hash_variant=asm)
     out = np.zeros((oh, ow), dtype_for(bits))
+    dev.keep_stages(True)
     dev.process_host(np.ascontiguousarray(y), out)
     stages = dev.read_stage(passes - 1)
     dev.close()

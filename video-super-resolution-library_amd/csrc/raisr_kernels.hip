@@ -79,6 +79,7 @@ struct PassParams {
     int bank_bytes;              // size of the fp32 bank (buffer-descriptor range)
     const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
     const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
+    int write_hash;              // fused kernel: also write the hash plane (introspection for tests)
 };
 
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
@@ -383,31 +384,18 @@ __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
 // AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
 // LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
-template <int R, typename T, bool AVX2ALL>
-__global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassParams P, GaussW gw,
-                                                  uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+//
+// hash_phase: the work of one tile once its LR window (origin (r0-6, c0-6), row stride LW) is in sL.  Returns, per
+// lane (= column c0+lane) and row j of the wave's R rows, hA = first hash (0xFF: pixel not filtered) and hB = the
+// AVX2 re-hash of an overlap column (0xFF elsewhere).  Ends with every wave past its last LDS read of sG.
+template <int R, bool AVX2ALL, int LW>
+__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, f2* sG,
+                                           const uint2* sTab, const uint16_t* sLut, int c0, int r0,
+                                           unsigned (&hA)[R], unsigned (&hB)[R])
 {
     constexpr int TH = 4 * R;
-    constexpr int LW = 76, LH = TH + 12;    // LR tile incl. 6-px halo
     constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
-    __shared__ float sL[LH * LW];
-    __shared__ f2 sG[GH * GW_];
-    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
-    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
-
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int bx, by;
-    xcd_tile(bx, by);
-    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
-
-    if constexpr (AVX2ALL) {
-        const uint2* src = reinterpret_cast<const uint2*>(P.lut_legacy);           // 4096 x u16 = 1024 x 8 B
-        for (int i = threadIdx.x; i < 1024; i += 256) reinterpret_cast<uint2*>(sLut)[i] = src[i];
-    } else {
-        if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
-    }
-    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
-    __syncthreads();
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
     {
         auto grad = [&](int ty, int tx) {
@@ -485,26 +473,23 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
         ad[j] = (holdAD[j] + curAD[j]) + t1AD[j];            // (Gb+Gc) + (Ga+Gd)
         bb[j] = (holdB[j] + curB[j]) + t1B[j];
     }
+    const bool inB = c >= P.b_begin && c < P.b_end;
     if constexpr (AVX2ALL) {
         const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, sLut};
-        const bool inB = c >= P.b_begin && c < P.b_end;
-        unsigned h1[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
             bool unused = false;
-            h1[j] = (unsigned)hash_px_impl<1>(ad[j].x, bb[j], ad[j].y, HQ, sTab, unused);
-        }
-#pragma unroll
-        for (int j = 0; j < R; j++) {
+            const unsigned h = (unsigned)hash_px_impl<1>(ad[j].x, bb[j], ad[j].y, HQ, sTab, unused);
             const int r = r0 + w * R + j;
-            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)(inB ? h1[j] : 0xFFu);
+            hA[j] = (r < P.H - kMargin && c < P.c_final && inB) ? h : 0xFFu;
+            hB[j] = 0xFFu;
         }
         return;
     }
     // AVX-512 flavour for every pixel of the lane as straight-line code (independent chains interleave);
     // the rare cases -- generic approximation-instruction inputs, AVX2 flavour of the tail columns -- follow.
     const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
-    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    const bool inA = c >= P.a_begin && c < P.a_end;
     unsigned h1[R];
     bool rare[R];
 #pragma unroll
@@ -516,15 +501,60 @@ __global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassP
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const int r = r0 + w * R + j;
+        hA[j] = 0xFFu; hB[j] = 0xFFu;
         if (r < P.H - kMargin && c < P.c_final) {
             unsigned h = h1[j];
             if (rare[j]) h = (unsigned)hash_px_generic(ad[j].x, bb[j], ad[j].y, HQ, sTab);
             if (inB) {                                       // the tail columns of AVX-512 mode
-                const unsigned hB = (unsigned)hash_px_legacy(ad[j].x, bb[j], ad[j].y, HQ, sTab);
-                if (inA) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;   // re-hashed tail column
-                else h = hB;
+                const unsigned hL = (unsigned)hash_px_legacy(ad[j].x, bb[j], ad[j].y, HQ, sTab);
+                if (inA) hB[j] = hL;                         // re-hashed tail column
+                else h = hL;
             }
-            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)(inA || inB ? h : 0xFFu);
+            hA[j] = (inA || inB) ? h : 0xFFu;
+        }
+    }
+}
+
+// stage the approximation tables of the hash flavour into LDS
+template <bool AVX2ALL>
+__device__ __forceinline__ void stage_hash_tables(const PassParams& P, uint2* sTab, uint16_t* sLut)
+{
+    if constexpr (AVX2ALL) {
+        const uint2* src = reinterpret_cast<const uint2*>(P.lut_legacy);           // 4096 x u16 = 1024 x 8 B
+        for (int i = threadIdx.x; i < 1024; i += 256) reinterpret_cast<uint2*>(sLut)[i] = src[i];
+    } else {
+        if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    }
+}
+
+template <int R, typename T, bool AVX2ALL>
+__global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassParams P, GaussW gw,
+                                                  uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+{
+    constexpr int TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;    // LR tile incl. 6-px halo
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[(TH + 10) * 74];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
+
+    stage_hash_tables<AVX2ALL>(P, sTab, sLut);
+    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    unsigned hA[R], hB[R];
+    hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        if (r < P.H - kMargin && c < P.c_final) {
+            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
+            if (hB[j] != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB[j];
         }
     }
 }
@@ -576,29 +606,15 @@ __device__ __forceinline__ float tree16(float acc)
     return acc;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
-                                                PassParams P, float* __restrict__ hr)
+// filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
+// (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
+template <int LW>
+__device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
+                                             int c0, int r0, float* __restrict__ hr)
 {
-    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
-    __shared__ float sL[LH * LW];
-    __shared__ uint8_t sH[TH * TW];         // first hash (0xFF = not filtered)
-    __shared__ uint8_t sH2[TH * TW];        // second hash of the overlap columns (0xFF elsewhere)
+    constexpr int TW = 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
-    int bx, by;
-    xcd_tile(bx, by);
-    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
-
-    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
-    for (int ty = w; ty < TH; ty += 4) {
-        const int r = r0 + ty, c = c0 + lane;
-        const bool in = r < P.H - kMargin && c < P.c_final;
-        sH[ty * TW + lane] = in ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
-        sH2[ty * TW + lane] = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : (uint8_t)0xFFu;
-    }
-    __syncthreads();
-
     int off[8];
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
@@ -666,6 +682,71 @@ __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const 
         const int c = c0 + 4 * l + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
+                                                PassParams P, float* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
+    __shared__ float sL[LH * LW];
+    __shared__ uint8_t sH[TH * TW];         // first hash (0xFF = not filtered)
+    __shared__ uint8_t sH2[TH * TW];        // second hash of the overlap columns (0xFF elsewhere)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
+    for (int ty = w; ty < TH; ty += 4) {
+        const int r = r0 + ty, c = c0 + lane;
+        const bool in = r < P.H - kMargin && c < P.c_final;
+        sH[ty * TW + lane] = in ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
+        sH2[ty * TW + lane] = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : (uint8_t)0xFFu;
+    }
+    __syncthreads();
+    filter_phase<LW>(P, sL, sH, sH2, c0, r0, hr);
+}
+
+// k_hashfilter: both stages of a 64 x 16 tile in one kernel.  The tensor/hash stage is fp32-VALU bound and the
+// filter stage vector-L1 bound; with workgroups of one kernel in different stages on the same CU the two
+// resources are busy at the same time, which separate launches only achieve by accident across streams.
+// One LR window (6-px halo, stride 77: odd for the filter's patch reads) serves both stages; the hashes go from
+// registers to LDS, and to the hash plane only when a test asks for it.
+template <typename T, bool AVX2ALL>
+__global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr, PassParams P, GaussW gw,
+                                                       uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+{
+    constexpr int R = 4, TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12;
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[(TH + 10) * 74];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
+    uint8_t* sH = reinterpret_cast<uint8_t*>(sG);            // the gradient tile is dead once the hashes exist
+    uint8_t* sH2 = sH + TH * TW;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    stage_hash_tables<AVX2ALL>(P, sTab, sLut);
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    unsigned hA[R], hB[R];
+    hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
+    __syncthreads();                                         // every wave is done reading sG
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        sH[(w * R + j) * TW + lane] = (uint8_t)hA[j];
+        sH2[(w * R + j) * TW + lane] = (uint8_t)hB[j];
+        const int r = r0 + w * R + j;
+        if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
+    }
+    __syncthreads();
+    filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -914,6 +995,8 @@ struct raisr_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // chroma lane of raisr_hip_process_host (overlaps the Y path)
+    bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    int keep_hash_plane = 0;                   // fused kernel also writes the hash plane (set by raisr_hip_debug_read_stage users)
     raisr_hip_config cfg{};
     int blending = RAISR_HIP_BLEND_COUNT;      // per-call BlendingMode (RNLProcess argument)
     bool configured = false;
@@ -1020,16 +1103,27 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     if (P.c_final > kMargin && H > 2 * kMargin) {
         constexpr int R = 4;        // rows per lane: 3..6 measure the same within noise, 8 is slower (occupancy)
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
-        timer_begin(c, "k_hash", s, slot);
-        if (P.a_end > P.a_begin)
-            hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
-        else                                                // asm=avx2: no 16-wide chunks at all
-            hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
-        timer_end(c, s, slot);
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
-        timer_begin(c, "k_filter", s, slot);
-        hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
-        timer_end(c, s, slot);
+        const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
+        if (c->fused) {
+            P.write_hash = c->keep_hash_plane;
+            timer_begin(c, "k_hashfilter", s, slot);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_hashfilter<TOut, false>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+            else
+                hipLaunchKernelGGL((k_hashfilter<TOut, true>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else {
+            timer_begin(c, "k_hash", s, slot);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+            else
+                hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_filter", s, slot);
+            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
+            timer_end(c, s, slot);
+        }
     }
     if (P.randomness) {
         dim3 gb((W + 63) / 64, (H + 3) / 4);
@@ -1111,6 +1205,7 @@ int raisr_hip_device_count(void)
 
 static int create_impl(raisr_hip_ctx* c)
 {
+    if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     // small shared tables
@@ -1498,6 +1593,13 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         }
         if (y_keep > 0) HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
     }
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_keep_stages(raisr_hip_ctx* c, int on)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    c->keep_hash_plane = on != 0;
     return RAISR_HIP_OK;
 }
 

@@ -100,6 +100,7 @@ def lib():
         L.raisr_hip_process_host.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
         L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_debug_keep_stages.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -303,6 +304,9 @@ class RaisrDevice:
 
     def synchronize(self):
         _check(lib().raisr_hip_synchronize(self._h), "raisr_hip_synchronize")
+
+    def keep_stages(self, on=True):
+        _check(lib().raisr_hip_debug_keep_stages(self._h, int(on)), "debug_keep_stages")
 
     def read_stage(self, pass_index=0):
         mode2 = self.cfg.passes == 2 and self.cfg.two_pass_mode == 2
