@@ -222,7 +222,10 @@ def main():
         roofline = None
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
         # dominant kernel: the fused tensor/hash + filter kernel (fp32 paths), the hash kernel of the binary16 pipeline
-        dom = "k_hash16" if CFG["asm"] == 5 else ("k_hashfilter" if "k_hashfilter" in kern else "k_hash")
+        if CFG["asm"] == 5:
+            dom = "k_hashfilter16" if "k_hashfilter16" in kern else "k_hash16"
+        else:
+            dom = "k_hashfilter" if "k_hashfilter" in kern else "k_hash"
         if dom in kern and kern[dom]["count"]:
             # with two passes the kernel runs twice per frame: one launch still processes one frame-pass
             avg_s = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3
@@ -251,7 +254,7 @@ def main():
                     px = ((c1 - 6) * (IN_H - 12) + zone_w * zone_h) / 2
                 else:
                     px = zone_w * zone_h
-                flop_px = HASH_FLOP_PER_PIXEL + (FILTER_FLOP_PER_PIXEL if dom == "k_hashfilter" else 0)
+                flop_px = HASH_FLOP_PER_PIXEL + (FILTER_FLOP_PER_PIXEL if dom.startswith("k_hashfilter") else 0)
                 tflops = px * flop_px / (iso[dom] * 1e-3) / 1e12
                 roofline["valu"] = {"kernel": dom, "isolated_launch_ms": round(iso[dom], 4),
                                     "flop_per_launch": int(px * flop_px), "achieved": round(tflops, 2),

@@ -133,24 +133,15 @@ __device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, cons
 // the same for all four pixel classes up to operand order of single additions -- then scaled by NF
 // in fp32 and rounded back (:197-221).
 // ------------------------------------------------------------------------------------------------
-template <int R, typename T>
-__global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
-                                                    uint8_t* __restrict__ hash_out)
+// hash16_phase: one tile's tensor + hash once its LR window (origin (r0-6, c0-6), row stride LW) is in sL; returns the
+// lane's R hashes (0xFF = pixel not filtered).
+template <int R, int LW>
+__device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& Q, const GaussW16& gw, const hf* sL, hf2* sG,
+                                             const uint16_t* sTab, int c0, int r0, unsigned (&hA)[R])
 {
     constexpr int TH = 4 * R;
-    constexpr int LW = 76, LH = TH + 12;
     constexpr int GW_ = 74, GH = TH + 10;
-    __shared__ hf sL[LH * LW];
-    __shared__ hf2 sG[GH * GW_];
-    __shared__ uint16_t sTab[3072];
-
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int bx, by;
-    xcd_tile(bx, by);
-    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
-    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
-    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);   // u8 -> binary16 is exact for 8-bit content
-    __syncthreads();
     for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
         const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
         const hf gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
@@ -211,11 +202,38 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
         const int r = r0 + w * R + j;
         const hf2 ad = (holdAD[j] + curAD[j]) + t1AD[j];
         const hf bb = (holdB[j] + curB[j]) + t1B[j];
+        hA[j] = 0xFFu;
         if (r < P.H - kMargin && c < P.c_final) {
             const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
-            const unsigned hA = (unsigned)hash_px16(a, b, d, Q, sTab);
-            hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA;
+            hA[j] = (unsigned)hash_px16(a, b, d, Q, sTab);
         }
+    }
+}
+
+template <int R, typename T>
+__global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
+                                                    uint8_t* __restrict__ hash_out)
+{
+    constexpr int TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;
+    __shared__ hf sL[LH * LW];
+    __shared__ hf2 sG[(TH + 10) * 74];
+    __shared__ uint16_t sTab[3072];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
+    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
+    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);   // u8 -> binary16 is exact for 8-bit content
+    __syncthreads();
+    unsigned hA[R];
+    hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA);
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        if (r < P.H - kMargin && c < P.c_final) hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA[j];
     }
 }
 
@@ -235,26 +253,15 @@ __device__ __forceinline__ hf row_ror_h(hf v)
     return h_bits((uint16_t)__builtin_amdgcn_update_dpp(0, bits, CTRL, 0xf, 0xf, false));
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
-                                                  PassParams P, Pass16 Q, uint16_t* __restrict__ hr)
+// filter16_phase: one 64 x 16 tile once its LR window is in LDS (sL points at window position (r0-5, c0-5), row
+// stride LW) and its hashes are in sH.
+template <int LW>
+__device__ __forceinline__ void filter16_phase(const PassParams& P, const Pass16& Q, const hf* sL, const uint8_t* sH,
+                                               int c0, int r0, uint16_t* __restrict__ hr)
 {
-    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;
-    __shared__ hf sL[LH * LW];
-    __shared__ uint8_t sH[TH * TW];
+    constexpr int TW = 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
-    int bx, by;
-    xcd_tile(bx, by);
-    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
-
-    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
-    for (int ty = w; ty < TH; ty += 4) {
-        const int r = r0 + ty, c = c0 + lane;
-        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
-    }
-    __syncthreads();
-
     int off0[4], off1[4];
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
@@ -303,6 +310,61 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = (uint16_t)keepb;
     }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
+                                                  PassParams P, Pass16 Q, uint16_t* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;
+    __shared__ hf sL[LH * LW];
+    __shared__ uint8_t sH[TH * TW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
+    for (int ty = w; ty < TH; ty += 4) {
+        const int r = r0 + ty, c = c0 + lane;
+        sH[ty * TW + lane] = (r < P.H - kMargin && c < P.c_final) ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
+    }
+    __syncthreads();
+    filter16_phase<LW>(P, Q, sL, sH, c0, r0, hr);
+}
+
+// k_hashfilter16: both binary16 stages of a tile in one launch (see k_hashfilter).
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
+                                                         uint8_t* __restrict__ hash_out, uint16_t* __restrict__ hr)
+{
+    constexpr int R = 4, TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12;
+    __shared__ hf sL[LH * LW];
+    __shared__ hf2 sG[(TH + 10) * 74];
+    __shared__ uint16_t sTab[3072];
+    uint8_t* sH = reinterpret_cast<uint8_t*>(sG);            // the gradient tile is dead once the hashes exist
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    unsigned hA[R];
+    hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA);
+    __syncthreads();                                         // every wave is done reading sG
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        sH[(w * R + j) * TW + lane] = (uint8_t)hA[j];
+        const int r = r0 + w * R + j;
+        if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA[j];
+    }
+    __syncthreads();
+    filter16_phase<LW>(P, Q, sL + LW + 1, sH, c0, r0, hr);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // k_blend16: CTCountOfBitsChangedSegment_AVX512FP16_16f (:258-355).  Columns below c_avx use the

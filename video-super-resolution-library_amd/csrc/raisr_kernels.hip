@@ -1155,12 +1155,19 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
-        timer_begin(c, "k_hash16", s, slot);
-        hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
-        timer_end(c, s, slot);
-        timer_begin(c, "k_filter16", s, slot);
-        hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
-        timer_end(c, s, slot);
+        if (c->fused) {
+            P.write_hash = c->keep_hash_plane;
+            timer_begin(c, "k_hashfilter16", s, slot);
+            hipLaunchKernelGGL((k_hashfilter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass], (uint16_t*)c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else {
+            timer_begin(c, "k_hash16", s, slot);
+            hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_filter16", s, slot);
+            hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
+            timer_end(c, s, slot);
+        }
     }
     if (P.randomness) {
         dim3 gr((W + 63) / 64, (H + 3) / 4);
