@@ -644,8 +644,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         float keep = 0.0f;
         const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
-#pragma unroll 4
-        for (int s = 0; s < 16; s++) {          // unroll 4 measured best (1: same, 8/16: slower -- code size / occupancy)
+#pragma unroll                                   // fully unrolled: the step offset folds into the LDS immediates (fused kernel: +2 % over
+        for (int s = 0; s < 16; s++) {          // unroll 4; in the stand-alone k_filter, whose occupancy it lowers, unroll 4 was better)
             const unsigned hA = sH[prow * TW + 4 * s + g];
             float res = RAISR_LDS_F(ctr, s);
             if (hA != 0xFFu) {
