@@ -648,7 +648,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         for (int s = 0; s < 16; s++) {          // unroll 4; in the stand-alone k_filter, whose occupancy it lowers, unroll 4 was better)
             const unsigned hA = sH[prow * TW + 4 * s + g];
             float res = RAISR_LDS_F(ctr, s);
-            if (hA != 0xFFu) {
+            {   // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
+                // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
                 const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
                 float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
@@ -1358,6 +1359,8 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     if (cfg->passes != 1 && cfg->passes != 2) return fail(RAISR_HIP_EINVAL, "passes must be 1 or 2");
     if (cfg->in_width <= 0 || cfg->in_height <= 0 || cfg->out_width <= 0 || cfg->out_height <= 0)
         return fail(RAISR_HIP_EINVAL, "bad plane size");
+    if (cfg->clamp_lo < 0 || cfg->clamp_hi <= cfg->clamp_lo || cfg->clamp_hi >= (1 << cfg->bits))
+        return fail(RAISR_HIP_EINVAL, "clamp range must satisfy 0 <= lo < hi < 2^bits");
     if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512 &&
         cfg->hash_variant != RAISR_HIP_HASH_FP16)
         return fail(RAISR_HIP_EINVAL, "unknown hash variant");
