@@ -597,6 +597,12 @@ __device__ __forceinline__ float row_ror(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v)      // DPP quad_perm: CTRL = a | b<<2 | c<<4 | d<<6, lane i of a quad reads lane CTRL_i
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float tree16(float acc)
 {
     acc = acc + row_ror<0x128>(acc);    // row_ror:8  -> r8[i] = a[i] + a[i+8]
@@ -644,23 +650,38 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         float keep = 0.0f;
         const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
-#pragma unroll                                   // fully unrolled: the step offset folds into the LDS immediates (fused kernel: +2 % over
-        for (int s = 0; s < 16; s++) {          // unroll 4; in the stand-alone k_filter, whose occupancy it lowers, unroll 4 was better)
-            const unsigned hA = sH[prow * TW + 4 * s + g];
-            float res = RAISR_LDS_F(ctr, s);
-            {   // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
+        // The 16 steps (4 adjacent pixels each) go in four groups {j, j+4, j+8, j+12}: the lane that keeps step s is
+        // l == s, so the four steps of a group end in four different quads of the pixel's 16 lanes.  Each step's
+        // accumulator is folded by the first two tree levels (row_ror 8, 4: every lane then holds r4[l & 3]), the four
+        // steps are merged quad-wise into one register (quad m <- step j+4m), and the last two levels, the accept
+        // test and the keep-select run once per group instead of once per step.  Same additions, same order.
+        const char* ctrq = ctr + 64 * (l >> 2);                // centre pixel of the step this lane's quad ends up with
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float part[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int s = j + 4 * m;
+                const unsigned hA = sH[prow * TW + 4 * s + g];
+                // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
                 // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
                 const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
                 float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
-                const float v = tree16(acc);
-                if (v > P.lo && v < P.hi) res = v;
+                acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
+                part[m] = acc + row_ror<0x124>(acc);           // r4[i] = r8[i] + r8[i+4]   (period 4 over the 16 lanes)
             }
-            {   // lane (g,l) keeps pixel column 4l+g: lanes with l == s, as a scalar mask (one VALU select, no compare)
-                const unsigned long long km = 0x0001000100010001ull << s;
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(km));
-            }
+            float v = part[0];
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[3]), "s"(0xf000f000f000f000ull));
+            v = v + quad_perm<0x4e>(v);                        // [2,3,0,1]: r2 = r4[i] + r4[i+2]
+            v = v + quad_perm<0xb1>(v);                        // [1,0,3,2]: r2[0] + r2[1]
+            float res = RAISR_LDS_F(ctrq, j);
+            if (v > P.lo && v < P.hi) res = v;
+            // lane (g,l) keeps pixel column 4l+g, i.e. step l: in group j those are the lanes with (l & 3) == j
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
         }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
