@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
     __shared__ hf sL[LH * LW];
     __shared__ hf2 sG[(TH + 10) * 74];
     __shared__ uint16_t sTab[3072];
-    uint8_t* sH = reinterpret_cast<uint8_t*>(sG);            // the gradient tile is dead once the hashes exist
+    __shared__ uint8_t sH[TH * TW];          // rows [4w, 4w+4) are written and read by wave w only: no barrier between the stages
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
@@ -353,7 +353,6 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
     __syncthreads();
     unsigned hA[R];
     hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA);
-    __syncthreads();                                         // every wave is done reading sG
     const int c = c0 + lane;
 #pragma unroll
     for (int j = 0; j < R; j++) {
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
         const int r = r0 + w * R + j;
         if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA[j];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     filter16_phase<LW>(P, Q, sL + LW + 1, sH, c0, r0, hr);
 }
 

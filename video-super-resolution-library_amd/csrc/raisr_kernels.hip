@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
     __shared__ f2 sG[(TH + 10) * 74];
     __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
     __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
-    uint8_t* sH = reinterpret_cast<uint8_t*>(sG);            // the gradient tile is dead once the hashes exist
-    uint8_t* sH2 = sH + TH * TW;
+    __shared__ uint8_t sH[TH * TW];          // first hash; rows [4w, 4w+4) are written AND read by wave w only
+    __shared__ uint8_t sH2[TH * TW];         // AVX2 re-hash of the overlap columns
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
@@ -758,7 +758,8 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
     __syncthreads();
     unsigned hA[R], hB[R];
     hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
-    __syncthreads();                                         // every wave is done reading sG
+    // A wave filters exactly the rows it hashed (rows [4w, 4w+4)), so no workgroup barrier separates the stages: the
+    // four waves of a tile drift apart and the VALU-bound and the L1-bound stage overlap inside the workgroup too.
     const int c = c0 + lane;
 #pragma unroll
     for (int j = 0; j < R; j++) {
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
         const int r = r0 + w * R + j;
         if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                         // LDS is in order within a wave; keep the compiler from reordering
     filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
 }
 
