@@ -4,32 +4,36 @@
 // Pipeline per RAISR pass (whole-frame semantics of the reference's processSegment(),
 // Library/Raisr.cpp:890-1289, run with threadcount=1):
 //
-//   k_resize   cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)      in  -> LR (sample type)
-//   k_hash     11x11 structure tensor + hash  (Raisr_AVX512.cpp:69-131,175-258;
-//              tail columns also Raisr_AVX256.cpp:393-472)                          LR  -> hash (u8) [+ tail re-hash]
-//   k_filter   hash-indexed 121-tap filter + accept test (Raisr_AVX512.cpp:134-149,
-//              Raisr.cpp:1196-1200)                                                 LR,hash -> HR (f32)
-//   k_blend    census-transform blend, clamp, narrow, borders
-//              (Raisr_AVX256.cpp:68-166, Raisr.cpp:999-1028,1252-1265)              LR,HR -> out
+//   k_resize      cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)       in -> LR (sample type)
+//   k_hashfilter  per 64 x 16 tile, one launch, two stages sharing one LR window in LDS:
+//                   hash stage    11x11 structure tensor + hash (Raisr_AVX512.cpp:69-131,175-258; tail columns
+//                                 also Raisr_AVX256.cpp:393-472)                        LR -> bucket per pixel (LDS)
+//                   filter stage  hash-indexed 121-tap filter + accept test
+//                                 (Raisr_AVX512.cpp:134-149, Raisr.cpp:1196-1200)       LR, bucket -> HR (f32)
+//   k_blend       census-transform blend, clamp, narrow, borders
+//                 (Raisr_AVX256.cpp:68-166, Raisr.cpp:999-1028,1252-1265)               LR, HR -> out
+//   (k_hash + k_filter are the same two stages as separate launches with the bucket plane in HBM: RAISR_HIP_FUSED=0.)
 //
 // Numeric contract: every floating-point operation below maps to exactly one IEEE-754 binary32
 // operation of the cited reference lines ("strict source" semantics).  This file MUST be built
 // with -ffp-contract=off and without fast-math; FMAs appear only where the reference has an
 // explicit fmadd intrinsic.
 //
-// (raisr_fp16_kernels.h holds the binary16 twins k_hash16 / k_filter16 / k_blend16 for the AVX512-FP16 numerics;
-//  k_blend_rand is the Randomness blending mode shared by both.)
+// (raisr_fp16_kernels.h holds the binary16 twins k_hashfilter16 / k_hash16 / k_filter16 / k_blend16 for the
+//  AVX512-FP16 numerics; k_blend_rand is the Randomness blending mode shared by both.)
 //
-// Design notes (MI355X): the work is fp32-VALU bound (~1 kFLOP per output pixel per pass against
+// Design notes (MI355X): the work is fp32-VALU bound (~1.3 kFLOP per output pixel per pass against
 // ~1.25 compulsory HBM bytes) and, in the filter stage, vector-L1 bound (512 B of coefficients per pixel),
-// so the kernels are organised around VALU/LDS/L1 efficiency and occupancy:
-//   * k_hash: one wave = 64 adjacent columns x R rows; gradients are computed once per tile into
+// so the kernels are organised around VALU/LDS/L1 efficiency:
+//   * hash stage: one wave = 64 adjacent columns x 4 rows; gradients are computed once per tile into
 //     LDS as (gx,gy) float2 so the inner loop is ds_read_b64 + v_pk_mul_f32 + v_pk_fma_f32 +
 //     v_fmac_f32 per (pixel, tap) with the Gaussian weight in an SGPR; column accumulators are
-//     folded in the reference's reduction-tree order as they complete.
-//   * k_filter: 16 lanes per pixel (one lane per accumulator lane of the reference's zmm), so a
-//     filter row is fetched as fully coalesced 64-byte segments and the 16->1 tree is four DPP
-//     row rotations -- exactly the reference's sumitup_ps_512 association.
+//     folded in the reference's reduction-tree order as they complete; the hash itself is straight-line code.
+//   * filter stage: 16 lanes per pixel (one lane per accumulator lane of the reference's zmm), so a
+//     filter row is fetched as fully coalesced 64-byte segments and the 16->1 tree is DPP row rotations and
+//     quad permutes -- exactly the reference's sumitup_ps_512 association.
+//   * both stages in one kernel: workgroups (and waves) of a CU are in different stages at any time, so the VALU-bound
+//     and the L1-bound stage overlap on every CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
