@@ -21,6 +21,7 @@ struct GaussW16 {
 
 struct Pass16 {
     const uint32_t* bank16;      // [hash][type][4 chunks][16 lanes] half2 = (f[32c+l], f[32c+l+16]), taps >= 121 are +0
+    int bank16_bytes;            // size of the binary16 bank (buffer-descriptor range)
     const uint16_t* tab16;       // rcpph T[1024], rsqrtph T0[1024], T1[1024]
     uint16_t qangle, qs0, qs1, qc0, qc1;   // binary16 bit patterns
     float nf;                    // NF_8 (fp32), Raisr_globals.h:208
@@ -270,42 +271,63 @@ __device__ __forceinline__ void filter16_phase(const PassParams& P, const Pass16
         off1[ch] = (k1 < kTaps) ? (k1 / 11) * LW + (k1 % 11) : 0;
     }
     const hf lo = (hf)P.lo, hi = (hf)P.hi;
+    // bounds-checked 32-bit addressing of the binary16 bank: an unfiltered pixel's hash (0xFF) points past it and
+    // loads +0, so its dot product is 0, fails the accept test (lo >= 0) and the pixel keeps LR -- no branch
+    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(Q.bank16), 0, Q.bank16_bytes, 0x00020000);
+    const unsigned bank_stride = (unsigned)P.pixel_types * 256u;           // bytes per hash bucket
+    const unsigned tcol = (P.pixel_types == 4) ? (unsigned)((g + 1) & 1) : 0u;   // (c-5)&1 with c = c0 + 4s + g, c0 even
 
 #pragma unroll 1
     for (int row = 0; row < 4; row++) {
         const int prow = 4 * w + row;
         const int r = r0 + prow;
         unsigned keepb = 0u;                                               // binary16 bits of the kept pixel
-        // pixel type of column c = c0 + 4s + g (c0 even): row part ((r-5)&1)*2, column part (c-5)&1 = (g+1)&1
-        const unsigned t = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((g + 1) & 1)) : 0u;
-        const uint32_t* frow = Q.bank16 + (t * 64u + (unsigned)l);
-        const unsigned bank_stride = (unsigned)P.pixel_types * 64u;        // half2 words per hash bucket
-#pragma unroll 4
-        for (int s = 0; s < 16; s++) {
-            const int pcol = 4 * s + g;
-            const unsigned hA = sH[prow * TW + pcol];
-            const int base = prow * LW + pcol;
-            const hf center = sL[base + 5 * LW + 5];
-            hf res = center;
-            if (hA != 0xFFu) {
-                const uint32_t* f = frow + __umul24(hA, bank_stride);
-                hf2 acc = (hf2){sL[base + off0[0]], sL[base + off1[0]]} * __builtin_bit_cast(hf2, f[0]);
+        const unsigned trow = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2) : 0u;
+        const unsigned row_lane_off = ((trow + tcol) * 64u + (unsigned)l) * 4u;
+        // LDS byte addresses of the lane's 8 taps and of the centre pixel for step 0; step s adds the immediate 8*s
+        const char* tp0[4];
+        const char* tp1[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+            tp0[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off0[ch]);
+            tp1[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off1[ch]);
+        }
+        const char* ctrq = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5) + 32 * (l >> 2);
+#define RAISR_LDS_H(p, s) (*reinterpret_cast<const hf*>((p) + 8 * (s)))
+        // steps grouped {j, j+4, j+8, j+12} as in filter_phase: two tree levels per step, quad-wise merge, the rest per group
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned part[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int s = j + 4 * m;
+                const unsigned hA = sH[prow * TW + 4 * s + g];
+                const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;
+                hf2 acc = (hf2){RAISR_LDS_H(tp0[0], s), RAISR_LDS_H(tp1[0], s)} *
+                          __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff, 0, 0));
 #pragma unroll
                 for (int ch = 1; ch < 4; ch++)
-                    acc = __builtin_elementwise_fma((hf2){sL[base + off0[ch]], sL[base + off1[ch]]}, __builtin_bit_cast(hf2, f[16 * ch]), acc);
+                    acc = __builtin_elementwise_fma((hf2){RAISR_LDS_H(tp0[ch], s), RAISR_LDS_H(tp1[ch], s)},
+                                                    __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff + 64u * ch, 0, 0)), acc);
                 hf v = acc.x + acc.y;                       // a[l] + a[l+16]
                 v = v + row_ror_h<0x128>(v);                // r16[i] + r16[i+8]
-                v = v + row_ror_h<0x124>(v);                // r8[i] + r8[i+4]
-                v = v + row_ror_h<0x122>(v);                // t[i] + t[i+2]
-                v = v + row_ror_h<0x121>(v);                // s0 + s1
-                if (v > lo && v < hi) res = v;
+                v = v + row_ror_h<0x124>(v);                // r8[i] + r8[i+4]   (period 4 over the 16 lanes)
+                part[m] = h_u(v);
             }
-            {   // lanes with l == s keep this step's pixel: scalar lane mask, one VALU select
-                const unsigned long long km = 0x0001000100010001ull << s;
-                const unsigned rb = h_u(res);
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keepb) : "v"(rb), "s"(km));
-            }
+            unsigned vb = part[0];
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[3]), "s"(0xf000f000f000f000ull));
+            hf v = h_bits((uint16_t)vb);
+            v = v + row_ror_h<0x4e>(v);                     // quad_perm [2,3,0,1]: t[i] + t[i+2]
+            v = v + row_ror_h<0xb1>(v);                     // quad_perm [1,0,3,2]: s0 + s1
+            hf res = RAISR_LDS_H(ctrq, j);
+            if (v > lo && v < hi) res = v;
+            const unsigned rb = h_u(res);
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keepb) : "v"(rb), "s"(0x1111111111111111ull << j));
         }
+#undef RAISR_LDS_H
         const int c = c0 + 4 * l + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = (uint16_t)keepb;
     }

@@ -1175,6 +1175,7 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     Pass16 Q{};
     const int rows = m.h.hashkeys * m.h.pixel_types;
     Q.bank16 = (const uint32_t*)((const char*)m.blob + kBlobHeader + blob_f32_bytes(rows));
+    Q.bank16_bytes = (int)blob_f16_bytes(rows);
     Q.tab16 = c->d_tab16;
     Q.qangle = m.h.qangle16; Q.qs0 = m.h.qstr16[0]; Q.qs1 = m.h.qstr16[1]; Q.qc0 = m.h.qcoh16[0]; Q.qc1 = m.h.qcoh16[1];
     { volatile float nf = 1.0f / (255.0f * 255.0f * 2.0f * 2.0f); Q.nf = nf; }
