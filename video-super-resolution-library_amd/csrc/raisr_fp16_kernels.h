@@ -83,15 +83,51 @@ __device__ __forceinline__ uint16_t rcpph_dev(uint16_t x, const uint16_t* tab)
     return (uint16_t)(sign | ((uint32_t)max(re, 0) << 10) | (t & 1023u));
 }
 
-__device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab)
+// generic composition (any input); kept out of line, only NaN / infinity reach it from the hash
+__device__ __attribute__((noinline)) uint16_t sqrt_ph_generic(uint16_t x, const uint16_t* tab)
 {
-    return h_bits(rcpph_dev(rsqrtph_dev(h_u(v), tab), tab));
+    return rcpph_dev(rsqrtph_dev(x, tab), tab);
 }
 
-// GetHashValue_AVX512FP16_16h_{8,32}Elements (Raisr_AVX512FP16.cpp:382-471,497-590)
-__device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, const uint16_t* tab)
+// VRCPPH(VRSQRTPH(v)), branch-free for everything finite (binary16 denormals are ordinary hash inputs: flat patches
+// give radicands and eigenvalues below 6e-5):
+//   positive (normal or denormal, normalised by a leading-zero count): y = VRSQRTPH(x) has the table mantissa
+//            and exponent te - half, always normal (exponent 7..27); VRCPPH(y) = table row of y's mantissa with
+//            exponent te2 + 15 - (te - half), in 2..23: none of the generic model's range checks can fire;
+//   +-0 -> +-inf -> +-0;   negative (normal or denormal) -> QNaN 0xfe00 -> 0xfe00;
+//   +-inf, NaN -> `rare`: the caller recomputes with the generic model.
+__device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab, bool& rare)
 {
-    const hf c100 = (hf)100.0f, one = (hf)1.0f, two = (hf)2.0f, four = (hf)4.0f;
+    const uint32_t x = h_u(v);
+    uint32_t m = x & 1023u;
+    int E = (int)((x >> 10) & 31u);
+    const int lz = __clz((int)(m | 1u)) - 21;                // m == 0 never takes the denormal values below
+    const bool den = E == 0;
+    m = den ? ((m << lz) & 1023u) : m;
+    E = den ? 1 - lz : E;
+    const int ue = E - 15, p = ue & 1, half = (ue - p) >> 1;
+    const uint32_t t = tab[1024 + 1024 * p + (int)m];
+    const uint32_t t2 = tab[t & 1023u];
+    const int re = (int)((t2 >> 10) & 31u) + 15 - (int)((t >> 10) & 31u) + half;
+    uint32_t z = ((uint32_t)re << 10) | (t2 & 1023u);
+    const bool zero = (x & 0x7fffu) == 0u;
+    const bool negative = (x & 0x8000u) != 0u;
+    z = negative ? 0xfe00u : z;
+    z = zero ? x : z;
+    rare |= ((x >> 10) & 31u) == 31u;
+    return h_bits((uint16_t)z);
+}
+
+// GetHashValue_AVX512FP16_16h_{8,32}Elements (Raisr_AVX512FP16.cpp:382-471,497-590).  FAST: branch-free square roots,
+// `rare` set when one of them saw an infinity or a NaN (the caller then calls the generic variant).
+// thresholds BY VALUE: a reference into the kernel-argument struct would force it into scratch for the out-of-line variant
+struct HashQ16 { uint16_t qangle, qs0, qs1, qc0, qc1; };
+
+template <bool FAST>
+__device__ __forceinline__ int hash_px16_impl(hf a, hf b, hf d, const HashQ16 Q, const uint16_t* tab, bool& rare)
+{
+    auto root = [&](hf v) { return FAST ? sqrt_ph(v, tab, rare) : h_bits(rcpph_dev(rsqrtph_dev(h_u(v), tab), tab)); };
+    const hf c100 = (hf)100.0f, one = (hf)1.0f;
     const hf pi = (hf)3.141592653f;
     const hf ONEQTR_PI = (hf)(3.14159265358979323846 / 4.0);
     const hf THRQTR_PI = (hf)(3.0 * 3.14159265358979323846 / 4.0);
@@ -99,9 +135,11 @@ __device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, cons
     a = a * c100; b = b * c100; d = d * c100;
     const hf T = a + d;
     const hf Dt = (a * d) - (b * b);
-    const hf rad = h_div(T * T, four) - Dt;
-    const hf s = sqrt_ph(rad, tab);
-    const hf hT = h_div(T, two);
+    // x / 4 and x / 2 are the same real numbers as x * 0.25 and x * 0.5, hence the same binary16 roundings
+    // (also into the denormal range): no division needed for these two
+    const hf rad = ((T * T) * (hf)0.25f) - Dt;
+    const hf s = root(rad);
+    const hf hT = T * (hf)0.5f;
     const hf L1 = hT + s, L2 = hT - s;
     const hf xx = (b < (hf)0.0f || b > (hf)0.0f) ? (L1 - d) : one;
     const hf ay = __builtin_fabsf16(b) + tiny;
@@ -115,7 +153,7 @@ __device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, cons
     const hf nang = (hf)-1.0f * ang;
     ang = (b < (hf)0.0f) ? nang : ang;
     ang = ang + ((ang < (hf)0.0f) ? pi : (hf)0.0f);
-    const hf sL1 = sqrt_ph(L1, tab), sL2 = sqrt_ph(L2, tab);
+    const hf sL1 = root(L1), sL2 = root(L2);
     const hf coh = h_div(sL1 - sL2, (sL1 + sL2) + near_zero);
     const hf str = h_div(L1, c100);
     const float fl = __builtin_floorf((float)(ang * h_bits(Q.qangle)));
@@ -124,6 +162,12 @@ __device__ __forceinline__ int hash_px16(hf a, hf b, hf d, const Pass16& Q, cons
     const int si = (int)(h_bits(Q.qs0) <= str) + (int)(h_bits(Q.qs1) <= str);
     const int ci = (int)(h_bits(Q.qc0) <= coh) + (int)(h_bits(Q.qc1) <= coh);
     return ai * 9 + si * 3 + ci;
+}
+
+__device__ __attribute__((noinline)) int hash_px16_generic(hf a, hf b, hf d, const HashQ16 Q, const uint16_t* tab)
+{
+    bool unused = false;
+    return hash_px16_impl<false>(a, b, d, Q, tab, unused);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -198,16 +242,18 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
     }
 
     const int c = c0 + lane;
+    const HashQ16 HQ = {Q.qangle, Q.qs0, Q.qs1, Q.qc0, Q.qc1};
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const int r = r0 + w * R + j;
         const hf2 ad = (holdAD[j] + curAD[j]) + t1AD[j];
         const hf bb = (holdB[j] + curB[j]) + t1B[j];
-        hA[j] = 0xFFu;
-        if (r < P.H - kMargin && c < P.c_final) {
-            const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
-            hA[j] = (unsigned)hash_px16(a, b, d, Q, sTab);
-        }
+        // straight-line for every pixel of the lane (the four chains interleave); out-of-zone pixels are masked afterwards
+        const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
+        bool rare = false;
+        unsigned h = (unsigned)hash_px16_impl<true>(a, b, d, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px16_generic(a, b, d, HQ, sTab);
+        hA[j] = (r < P.H - kMargin && c < P.c_final) ? h : 0xFFu;
     }
 }
 
