@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration; the bench line is C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=30)
+    ap.add_argument("--cpu-sample-frames", type=int, default=100, help="bounded CPU-baseline sample (~10-15 s on 16 cores)")
     ap.add_argument("--frame-kind", default="natural", choices=["natural", "constant", "random", "checker"])
     return ap.parse_args()
 
