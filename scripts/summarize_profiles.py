@@ -30,6 +30,8 @@ if f:
     for r in csv.DictReader(open(f[0])):
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
     lines.append("")
+    import shutil
+    shutil.copyfile(f[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))      # the raw rocprofv3 --stats table
 ev = os.path.join(src, "bench_events.json")
 if os.path.exists(ev):
     try:
