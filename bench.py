@@ -128,13 +128,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; ranks beyond the visible devices wrap around (only meaningful for the 2-ranks-on-1-GPU
+    # plumbing test, which also swaps RCCL for gloo via RAISR_BENCH_BACKEND -- RCCL refuses two ranks on one device)
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     # launched by torch.distributed.run (RANK set) -> always go through RCCL, even with one rank, so the
     # collective path of the N-GPU runs is the one exercised by a 1-GPU torchrun smoke test
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RAISR_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- model: rank 0 reads the files and packs the device blob; RCCL broadcast to the others ----
     passes = CFG["passes"]
@@ -151,7 +158,7 @@ def main():
 
     lanes = []
     for _ in range(args.lanes):
-        d = R.RaisrDevice(local_rank)
+        d = R.RaisrDevice(gpu)
         for p in range(passes):
             d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
         d.configure(IN_W, IN_H, OUT_W, OUT_H, bits=bits, passes=passes, mode=CFG["mode"], hash_variant=CFG["asm"])

@@ -45,3 +45,17 @@ def test_bench_plain_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in j["cpu_baseline"], k
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_plumbing():
+    """world_size 2 on the one GPU of the test box (gloo instead of RCCL, which refuses two ranks on one device): rank 1
+    receives the filter bank by broadcast, the ranks own disjoint frames, the time is the max over ranks, one JSON line."""
+    env = dict(os.environ, RAISR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _one_json_line(out.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "frame-shard x2"
+    assert j["value"] > 0 and abs(j["value"] - j["config"]["fps"] * 3840 * 2160 / 1e6) < 1.0
