@@ -46,3 +46,68 @@ def test_pure_host_entry_points_work_without_a_gpu():
     assert hdr[:4].tobytes() == b"RASR" and hdr[4:16].view(np.int32).tolist() == [216, 4, 24]
     assert np.float32(hdr[16:20].view(np.float32)[0]) == np.float32(24) / np.float32(3.141592653)
     assert b"raisr-hip" in L.raisr_hip_version()
+
+
+def test_headers_are_plain_c_and_link_from_a_c_program(tmp_path):
+    """The drop-in headers must be consumable from C (FFmpeg's vf_raisr.c is C): compile a C translation unit against
+    include/raisr/RaisrHandler.h + include/raisr_hip.h with gcc, link it to the library and run its GPU-free calls."""
+    import subprocess
+    import raisr_hip as R
+    R.build()
+    libdir = os.path.join(ROOT, "video-super-resolution-library_amd")
+    src = tmp_path / "c_client.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include <raisr/RaisrHandler.h>
+#include <raisr_hip.h>
+int main(void) {
+    VideoDataType v; memset(&v, 0, sizeof v);
+    raisr_hip_band b[4];
+    if (sizeof(VideoDataType) != sizeof(void *) + 4 * sizeof(unsigned)) return 2;
+    if (HIP != 6 || AVX512_FP16 != 5 || RNLErrorBadParameter != (int)0x80001002) return 3;
+    if (raisr_hip_plan_bands(1080, 2160, 1, 4, b) != 4 || b[3].keep_begin + b[3].keep_count != 2160) return 4;
+    if (!strstr(raisr_hip_version(), "raisr-hip")) return 5;
+    /* a folder without a config file must be refused before any GPU work (Raisr.cpp:1531-1539) */
+    if (RNLHandler_Init("/nonexistent-model-folder", 2.0f, 8, VideoRange, 20, AVX512, 1, 1) != RNLErrorBadParameter) return 6;
+    if (RNLHandler_Process(&v, &v, &v, &v, &v, &v, CountOfBitsChanged) != RNLErrorBadParameter) return 7;
+    puts("c-client-ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "c_client"
+    cc = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+          f"-L{libdir}", "-lraisr_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    out = subprocess.run(cc, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "c-client-ok" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-500:])
+
+
+def test_cpp_flavour_compiles_with_default_arguments(tmp_path):
+    """include/raisr/Raisr.h from C++ with the reference's default arguments (Library/Raisr.h:14-33)."""
+    import subprocess
+    import raisr_hip as R
+    R.build()
+    libdir = os.path.join(ROOT, "video-super-resolution-library_amd")
+    src = tmp_path / "cpp_client.cpp"
+    src.write_text(r'''
+#include <iostream>
+#include <raisr/Raisr.h>
+int main() {
+    std::string folder = "/nonexistent-model-folder";
+    if (RNLInit(folder, 2.0f) != RNLErrorBadParameter) return 2;           // bits=8, VideoRange, 20 threads, AVX512, 1 pass
+    VideoDataType v{};
+    if (RNLProcess(&v, &v, &v, &v, &v, &v) != RNLErrorBadParameter) return 3;   // blending defaults to CountOfBitsChanged
+    if (RNLDeinit() != RNLErrorNone) return 4;
+    std::cout << "cpp-client-ok\n";
+    return 0;
+}
+''')
+    exe = tmp_path / "cpp_client"
+    cc = ["g++", "-std=c++17", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+          f"-L{libdir}", "-lraisr_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    out = subprocess.run(cc, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "cpp-client-ok" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-500:])
