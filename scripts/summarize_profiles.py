@@ -63,6 +63,27 @@ if pmc:
               "  kernels wrote -- 41.5 MB per launch at the very least (the 4 MiB L2s cannot hold them; Infinity-Cache hits are",
               "  counted) -- and FETCH_SIZE reports half of that: the gfx950 half-count (128-B requests tallied at 64 B) applies to",
               "  these row-coalesced loads too, so FETCH_SIZE is doubled below, as the guide prescribes.", ""]
+    # derived: VALU issue rate and LDS conflict share, per kernel, from the isolated (--lanes 1) durations of bench.py
+    iso = {}
+    try:
+        iso = json.loads(open(ev).read().strip().splitlines()[-1]).get("kernels_isolated_ms", {})
+    except Exception:
+        pass
+    alias = {"k_resize2x": "k_resize"}
+    rows = []
+    for k, v in pmc.items():
+        t_ms = iso.get(alias.get(k, k))
+        if t_ms and "SQ_INSTS_VALU" in v:
+            rate = v["SQ_INSTS_VALU"] / (t_ms * 1e-3) / 1e9
+            conf = 100.0 * v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"] if v.get("SQ_LDS_IDX_ACTIVE") else 0.0
+            l2 = 100.0 * v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 1.0))
+            rows.append(f"| {k} | {t_ms * 1e3:.1f} | {v['SQ_INSTS_VALU'] / 1e6:.1f} | {rate:.0f} | {100 * rate / 911:.0f} % | {conf:.1f} % | {l2:.1f} % |")
+    if rows:
+        lines += ["## Derived (isolated launch, one lane)", "",
+                  "| kernel | isolated us | VALU wave-inst (M) | G wave-inst/s | of the 911 G/s `v_fma_f32` probe rate | LDS cycles lost to bank conflicts | L2 hit rate |",
+                  "|---|---|---|---|---|---|---|"] + rows + ["",
+                  "(packed-fp32 instructions count once here but occupy two issue slots, so the tensor-heavy kernel's slot utilisation is",
+                  "higher than its instruction rate suggests: see DESIGN.md s5.)", ""]
     traffic = {}
     for k, v in pmc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
