@@ -138,3 +138,32 @@ def test_rnlhandler_chroma_layouts(layout, cw_div, ch_div):
     assert np.array_equal(oy, oracle_y(y, ("x", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False)))
     assert np.array_equal(ou, O.resize(u, ou.shape[1], ou.shape[0]).astype(np.uint8))
     assert np.array_equal(ov, O.resize(v, ov.shape[1], ov.shape[0]).astype(np.uint8))
+
+
+def test_context_lifecycle_does_not_leak_device_memory():
+    """FFmpeg re-creates the filter per stream: Init/SetRes/Process/Deinit cycles and raw context create/destroy must
+    hand all HBM back (free memory before == after, within allocator granularity)."""
+    import raisr_hip as R
+    import synth
+    import torch
+    torch.cuda.synchronize()
+    y = synth.natural_y(320, 180, 8, seed=1)
+    c = synth.chroma(160, 90, 8)
+
+    def cycle():
+        oy, ou, ov = R.upscale_frame_host(y, c, c, folder("filters_2x/filters_highres"), ratio=2.0, bits=8, asm_type=R.AVX512, passes=2, mode=1)
+        dev = R.RaisrDevice(0)
+        dev.set_model_from_folder(folder("filters_2x/filters_highres"), 8, 1)
+        dev.configure(320, 180, 640, 360, bits=8)
+        out = np.zeros((360, 640), np.uint8)
+        dev.process_host(y, out)
+        dev.close()
+        return oy, out
+
+    cycle()                                   # first use pays one-time runtime allocations
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)

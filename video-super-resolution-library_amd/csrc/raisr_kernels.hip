@@ -39,7 +39,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/raisr_hip.h"
@@ -1238,11 +1240,76 @@ int raisr_hip_device_count(void)
     return n;
 }
 
+// Streams and the host-plane staging buffer are recycled through process-wide pools instead of being destroyed with
+// their context: hosts such as FFmpeg re-create the filter per clip, and every create/destroy cycle should leave the
+// device exactly as it found it (tests/test_gpu_host_api.py::test_context_lifecycle_does_not_leak_device_memory).
+static std::mutex g_pool_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;      // (device, idle stream)
+
+static int pool_get_stream(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); i++)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return RAISR_HIP_OK;
+            }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return RAISR_HIP_OK;
+}
+
+static void pool_put_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_stream_pool.emplace_back(device, s);
+}
+
+struct StageBuf { int device; void* ptr; size_t bytes; };
+static std::vector<StageBuf> g_stage_pool;
+
+static void* pool_get_stage(int device, size_t need, size_t* got)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_stage_pool.size(); i++)
+            if (g_stage_pool[i].device == device && g_stage_pool[i].bytes >= need) {
+                void* p = g_stage_pool[i].ptr; *got = g_stage_pool[i].bytes;
+                g_stage_pool.erase(g_stage_pool.begin() + (long)i);
+                return p;
+            }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return nullptr;
+    *got = need;
+    return p;
+}
+
+static void pool_put_stage(int device, void* p, size_t bytes)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_stage_pool.size() >= 16) {               // bound the idle set: drop the smallest buffer
+        size_t k = 0;
+        for (size_t i = 1; i < g_stage_pool.size(); i++) if (g_stage_pool[i].bytes < g_stage_pool[k].bytes) k = i;
+        if (g_stage_pool[k].bytes < bytes) { (void)hipFree(g_stage_pool[k].ptr); g_stage_pool[k] = {device, p, bytes}; }
+        else (void)hipFree(p);
+        return;
+    }
+    g_stage_pool.push_back({device, p, bytes});
+}
+
 static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    int rc = pool_get_stream(c->device, &c->stream);
+    if (rc) return rc;
+    rc = pool_get_stream(c->device, &c->stream2);
+    if (rc) return rc;
     // small shared tables
     std::vector<uint2> tab(128);
     for (int i = 0; i < 64; i++) { tab[i] = make_uint2(X86_RCP14_C0[i], X86_RCP14_C1[i]); tab[64 + i] = make_uint2(X86_RSQRT14_C0[i], X86_RSQRT14_C1[i]); }
@@ -1296,9 +1363,9 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
-    if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
+    pool_put_stream(c->device, c->stream);
+    pool_put_stream(c->device, c->stream2);
     delete c;
 }
 
@@ -1559,6 +1626,14 @@ int raisr_hip_plan_bands(int in_height, int out_height, int passes, int nbands, 
     return K;
 }
 
+// 2-D plane copy; contiguous planes (pitch == row bytes on both sides) go as one 1-D copy
+static hipError_t copy_plane(void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes, size_t rows,
+                             hipMemcpyKind kind, hipStream_t s)
+{
+    if (dpitch == row_bytes && spitch == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
+}
+
 int raisr_hip_process_host(raisr_hip_ctx* c,
                            const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
                            const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
@@ -1597,10 +1672,10 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     const size_t off_iu = al(iy), off_iv = off_iu + al(ic), off_oy = off_iv + al(ic), off_ou = off_oy + al(oy), off_ov = off_ou + al(oc);
     const size_t total = off_ov + al(oc);
     if (c->d_stage_bytes < total) {
-        if (c->d_stage) (void)hipFree(c->d_stage);
-        c->d_stage = nullptr; c->d_stage_bytes = 0;
-        if (hipMalloc(&c->d_stage, total) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "staging alloc");
-        c->d_stage_bytes = total;
+        pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
+        c->d_stage_bytes = 0;
+        c->d_stage = pool_get_stage(c->device, total, &c->d_stage_bytes);
+        if (!c->d_stage) return fail(RAISR_HIP_ENOMEM, "staging alloc");
     }
     char* d = (char*)c->d_stage;
     hipStream_t s = c->stream, s2 = c->stream2;
@@ -1609,14 +1684,14 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
     const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
     if (do_up) {
-        HIP_TRY(hipMemcpy2DAsync(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
+        HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
         if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
-            HIP_TRY(hipMemcpy2DAsync(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
+            HIP_TRY(copy_plane(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
         int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
         if (rc) return rc;
         if (chroma) {
-            HIP_TRY(hipMemcpy2DAsync(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
-            HIP_TRY(hipMemcpy2DAsync(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
             if (rc) return rc;
             rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
@@ -1625,10 +1700,10 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     }
     if (do_down) {
         if (chroma && c_keep > 0) {
-            HIP_TRY(hipMemcpy2DAsync(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
-            HIP_TRY(hipMemcpy2DAsync(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
         }
-        if (y_keep > 0) HIP_TRY(hipMemcpy2DAsync(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
+        if (y_keep > 0) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
     }
     return RAISR_HIP_OK;
 }
