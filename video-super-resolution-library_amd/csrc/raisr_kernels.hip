@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);       // group of 4 output columns
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int bx, by;
+    xcd_tile(bx, by);                                         // vertically adjacent blocks share input rows: keep them on one XCD
+    const int t = bx * 64 + (threadIdx.x & 63);               // group of 4 output columns
+    const int y = by * 4 + (threadIdx.x >> 6);
     const int x0 = 4 * t;
     if (x0 >= R.dw || y >= R.dh) return;
     const int sy = y >> 1;
