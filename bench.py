@@ -266,7 +266,10 @@ def main():
                 roofline["valu"] = {"kernel": dom, "isolated_launch_ms": round(iso[dom], 4),
                                     "flop_per_launch": int(px * flop_px), "achieved": round(tflops, 2),
                                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s (fp32 VALU)",
-                                    "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4)}
+                                    "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4),
+                                    # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
+                                    "sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)}
+                roofline["binding"] = "fp32-valu"
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
