@@ -9,7 +9,8 @@
  *   raisr_hip_set_model      <->  result of ReadTrainedData    Library/Raisr.cpp:246-433
  *   raisr_hip_configure      <->  RNLInit parameter state      Library/Raisr.cpp:1409-1679
  *                                 + RNLSetRes resources         Library/Raisr.cpp:1681-1829
- * The reference-compatible C API (RNLHandler_*, include/RaisrHandler.h) is implemented on top of
+ *   raisr_hip_plan_bands     <->  band/zone arithmetic         Library/Raisr.cpp:1738-1779
+ * The reference-compatible C API (RNLHandler_*, include/raisr/RaisrHandler.h) is implemented on top of
  * these entry points in csrc/raisr_api.cpp; a foreign-language binding (ctypes, cgo, JNI) can bind
  * either layer.
  *
