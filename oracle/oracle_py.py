@@ -32,7 +32,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libraisr_oracle.so")
+        so = os.environ.get("RAISR_ORACLE_SO") or os.path.join(_HERE, "libraisr_oracle.so")   # override: compiler cross-check
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)

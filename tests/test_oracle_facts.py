@@ -119,3 +119,41 @@ def test_vectorised_gtwg_row_equals_the_scalar_form():
             for c in (6, 7, 20, 41, 57):
                 L.ora_gtwg_both(plane.ctypes.data, 64, r, c, bits, out.ctypes.data)
                 assert np.array_equal(out[:3].view(np.uint32), out[3:].view(np.uint32)), (bits, r, c, out)
+
+
+def test_oracle_bits_do_not_depend_on_the_compiler(tmp_path):
+    """The oracle's contract is one IEEE operation per source operation, so another compiler at another optimisation
+    level, without AVX2/FMA code generation and without OpenMP, must give the same digests: builds the oracle with
+    clang -O1 for plain x86-64 and compares a few cases with the committed fixtures."""
+    import shutil
+    import subprocess
+    import sys
+    clang = shutil.which("clang") or "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no second compiler")
+    so = tmp_path / "libraisr_oracle_alt.so"
+    src = [os.path.join(ROOT, "oracle", f) for f in ("raisr_oracle.c", "raisr_oracle_fp16.c")]
+    cc = [clang, "-O1", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas", "-shared", "-o", str(so)] + src + ["-lm"]
+    out = subprocess.run(cc, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    code = r'''
+import hashlib, json, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, "video-super-resolution-library_amd")
+from common import CASES, oracle_y
+import synth
+got = {}
+for case in CASES:
+    if case[0] not in ("2x_highres_8b_1p_avx512", "2x_lowres_8b_1p_avx2", "1.5x_denoise_8b_2p_m2_fp16", "2x_highres_10b_2p_m1_full"):
+        continue
+    for nm, fr in (("natural", synth.natural_y(96, 64, case[3], seed=4242)), ("random", synth.random_y(96, 64, case[3], seed=99))):
+        got[f"{case[0]}/{nm}"] = hashlib.sha256(oracle_y(fr, case).tobytes()).hexdigest()
+print(json.dumps(got))
+'''
+    env = dict(os.environ, RAISR_ORACLE_SO=str(so), OMP_NUM_THREADS="1")
+    run = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = json.loads(run.stdout.strip().splitlines()[-1])
+    want = json.load(open(os.path.join(ROOT, "tests/golden/oracle_digests.json")))
+    assert len(got) == 8
+    for k, v in got.items():
+        assert want[k] == v, k
