@@ -1,6 +1,8 @@
 """-m gpu: seeded fuzz over geometry and options -- widths/heights that are not multiples of any tile or chunk size
 (64-column tiles, 16-row tiles, 8/16/32-column hash chunks, 2- and 3-row upscale periods), every numerics flavour,
 pass count / mode, range, bit depth and blending mode -- HIP path vs oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,7 +12,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _has_model(fold, bits, passes):
-    import os
     suffix = "_2" if passes == 2 else ""
     return os.path.exists(os.path.join(folder(fold), f"filterbin_2_{bits}{suffix}"))
 
@@ -39,7 +40,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(48, 20260928), ids=lambda c: f"{c[0].split('/')[1]}_{c[1][0]}-{c[1][1]}_{c[2]}x{c[3]}_{c[4]}b_a{c[5]}_p{c[6]}m{c[7]}_{'f' if c[8] else 'v'}_b{c[9]}_{c[10]}")
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("RAISR_FUZZ_N", "48")), int(os.environ.get("RAISR_FUZZ_SEED", "20260928"))), ids=lambda c: f"{c[0].split('/')[1]}_{c[1][0]}-{c[1][1]}_{c[2]}x{c[3]}_{c[4]}b_a{c[5]}_p{c[6]}m{c[7]}_{'f' if c[8] else 'v'}_b{c[9]}_{c[10]}")
 def test_fuzz_case(case):
     import oracle_py as O
     import raisr_hip as R
