@@ -11,6 +11,10 @@ from common import folder, dtype_for
 pytestmark = pytest.mark.gpu
 
 
+MAX_W = int(os.environ.get("RAISR_FUZZ_MAX_W", "150"))      # one-off wider sweeps: RAISR_FUZZ_N / _SEED / _MAX_W / _MAX_H
+MAX_H = int(os.environ.get("RAISR_FUZZ_MAX_H", "110"))
+
+
 def _has_model(fold, bits, passes):
     suffix = "_2" if passes == 2 else ""
     return os.path.exists(os.path.join(folder(fold), f"filterbin_2_{bits}{suffix}"))
@@ -21,7 +25,7 @@ def _cases(n, seed):
     out = []
     while len(out) < n:
         ratio = (2, 1) if rng.random() < 0.65 else (3, 2)
-        w = int(rng.integers(7, 150)); h = int(rng.integers(7, 110))
+        w = int(rng.integers(7, MAX_W)); h = int(rng.integers(7, MAX_H))
         if ratio == (3, 2):
             w -= w % 2; h -= h % 2                  # 1.5x: even input sizes give integer output sizes
         bits = 10 if (ratio == (2, 1) and rng.random() < 0.25) else 8
