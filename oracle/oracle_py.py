@@ -29,10 +29,38 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+_ISA = "x86-64-v3 (AVX2)"
+
+
+def _host_has_avx512():
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return False
+    return all(f in flags for f in ("avx512f", "avx512vl", "avx512dq", "avx512bw"))
+
+
+def isa():
+    """Vector ISA the loaded oracle build was compiled for (reported by bench.py's cpu_baseline)."""
+    lib()
+    return _ISA
+
+
 def lib():
-    global _LIB
+    global _LIB, _ISA
     if _LIB is None:
-        so = os.environ.get("RAISR_ORACLE_SO") or os.path.join(_HERE, "libraisr_oracle.so")   # override: compiler cross-check
+        so = os.environ.get("RAISR_ORACLE_SO")                 # override: compiler cross-check
+        if not so:
+            # RAISR_ORACLE_ISA: "avx2" (default; what the parity tests use everywhere), "avx512", or "auto" = the
+            # AVX-512 build of the same sources when this host executes it (bench.py's CPU baseline)
+            want = os.environ.get("RAISR_ORACLE_ISA", "avx2")
+            if want == "avx512" or (want == "auto" and _host_has_avx512()):
+                so = os.path.join(_HERE, "libraisr_oracle_avx512.so")
+                _ISA = "x86-64-v4 (AVX-512, 512-bit vectors)"
+            else:
+                so = os.path.join(_HERE, "libraisr_oracle.so")
+        else:
+            _ISA = "custom build " + os.path.basename(so)
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)

@@ -21,7 +21,7 @@ def _one_json_line(stdout):
 def test_bench_under_torchrun_single_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "3", "--warmup", "1", "--frames-per-step", "6", "--no-cpu-baseline"]
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--frames-per-step", "6", "--no-cpu-baseline", "--no-extras"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _one_json_line(out.stdout)
@@ -32,13 +32,20 @@ def test_bench_under_torchrun_single_rank():
 
 def test_bench_plain_contract_fields():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames-per-step", "6",
-           "--cpu-sample-frames", "2"]
+           "--cpu-sample-frames", "2", "--extra-frames", "8"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _one_json_line(out.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "c3_2pass", "end_to_end", "parity"):
         assert k in j, k
+    # the side legs: 2-pass (north_star's target config), host->host through the plugin API, parity vs the oracle
+    assert j["c3_2pass"]["value"] > 0 and j["c3_2pass"]["unit"] == "MP/s"
+    assert j["end_to_end"]["value"] > 0 and "RNLHandler_Process" in j["end_to_end"]["what"]
+    assert j["parity"]["mismatches"] == 0 and j["parity"]["psnr"] == "inf" and j["parity"]["pixels"] == 3840 * 2160
+    if "stream" in j:
+        assert j["stream"]["value"] > 0
+    assert "AVX" in j["cpu_baseline"]["sample"]                       # names the ISA the CPU leg was built for
     assert j["config"]["workload"].startswith("C2")
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in j["roofline"], k
@@ -53,9 +60,35 @@ def test_bench_two_ranks_on_one_gpu_plumbing():
     env = dict(os.environ, RAISR_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "8", "--no-cpu-baseline"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "8", "--no-cpu-baseline", "--no-extras"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _one_json_line(out.stdout)
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "frame-shard x2"
     assert j["value"] > 0 and abs(j["value"] - j["config"]["fps"] * 3840 * 2160 / 1e6) < 1.0
+
+
+def test_bench_gpus_flag_is_honoured_or_fails_loudly():
+    """`python bench.py --gpus 2` (no torchrun around it) must start two ranks itself; on a box with fewer than two
+    devices it has to fail -- never print a line for a world size it did not run."""
+    import torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "8",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if torch.cuda.device_count() >= 2:
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    else:
+        assert out.returncode != 0
+        assert not lines, lines
+        assert "needs 2 visible devices" in (out.stderr + out.stdout)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "8", "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

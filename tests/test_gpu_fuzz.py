@@ -44,7 +44,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(int(os.environ.get("RAISR_FUZZ_N", "48")), int(os.environ.get("RAISR_FUZZ_SEED", "20260928"))), ids=lambda c: f"{c[0].split('/')[1]}_{c[1][0]}-{c[1][1]}_{c[2]}x{c[3]}_{c[4]}b_a{c[5]}_p{c[6]}m{c[7]}_{'f' if c[8] else 'v'}_b{c[9]}_{c[10]}")
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("RAISR_FUZZ_N", "240")), int(os.environ.get("RAISR_FUZZ_SEED", "20260928"))), ids=lambda c: f"{c[0].split('/')[1]}_{c[1][0]}-{c[1][1]}_{c[2]}x{c[3]}_{c[4]}b_a{c[5]}_p{c[6]}m{c[7]}_{'f' if c[8] else 'v'}_b{c[9]}_{c[10]}")
 def test_fuzz_case(case):
     import oracle_py as O
     import raisr_hip as R

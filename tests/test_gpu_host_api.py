@@ -167,3 +167,86 @@ def test_context_lifecycle_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_rnlprocess_rejects_frames_that_differ_from_setres_geometry():
+    """The host copies are asynchronous DMAs sized by RNLSetRes: a smaller plane, or a step shorter than a row, must be
+    refused instead of read/written out of bounds (the reference trusts the caller here)."""
+    import raisr_hip as R
+    import synth
+    w, h = 96, 64
+    y = synth.natural_y(w, h, 8, seed=1)
+    c = synth.chroma(w // 2, h // 2, 8)
+    oy = np.zeros((2 * h, 2 * w), np.uint8); ou = np.zeros((h, w), np.uint8); ov = np.zeros((h, w), np.uint8)
+    assert R.RNLHandler_Init(folder("filters_2x/filters_highres"), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        assert R.RNLHandler_SetRes((y, c, c), (oy, ou, ov)) == 0
+        assert R.RNLHandler_Process((y, c, c), (oy, ou, ov)) == 0
+        small = synth.natural_y(w - 16, h, 8, seed=1)
+        assert R.RNLHandler_Process((small, c, c), (oy, ou, ov)) == R.RNLErrorBadParameter
+        short = synth.natural_y(w, h - 2, 8, seed=1)
+        assert R.RNLHandler_Process((short, c, c), (oy, ou, ov)) == R.RNLErrorBadParameter
+        assert R.RNLHandler_Process((y, c, c), (oy[:-2], ou, ov)) == R.RNLErrorBadParameter
+        assert R.RNLHandler_Process((y, c, c[:, :-2]), (oy, ou, ov)) == R.RNLErrorBadParameter
+        # step shorter than one row of samples
+        d = [R._vdt(p) for p in (y, c, c, oy, ou, ov)]
+        d[0].step = w - 1
+        import ctypes
+        assert R.lib().RNLHandler_Process(*[ctypes.byref(x) for x in d], R.CountOfBitsChanged) == R.RNLErrorBadParameter
+        assert R.RNLHandler_Process((y, c, c), (oy, ou, ov)) == 0          # still usable afterwards
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+
+
+def test_failed_reinit_leaves_the_library_uninitialised(tmp_path):
+    """A second RNLInit that fails must not leave the first one's device context running with the new parameters."""
+    import raisr_hip as R
+    import synth
+    w, h = 64, 48
+    y = synth.natural_y(w, h, 8, seed=2)
+    c = synth.chroma(w // 2, h // 2, 8)
+    oy = np.zeros((2 * h, 2 * w), np.uint8); ou = np.zeros((h, w), np.uint8); ov = np.zeros((h, w), np.uint8)
+    assert R.RNLHandler_Init(folder("filters_2x/filters_highres"), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    assert R.RNLHandler_SetRes((y, c, c), (oy, ou, ov)) == 0
+    assert R.RNLHandler_Init(str(tmp_path / "no_such_folder"), 2.0, 10, R.FullRange, 20, R.AVX512, 2, 1) != 0
+    assert R.RNLHandler_SetRes((y, c, c), (oy, ou, ov)) == R.RNLErrorBadParameter
+    assert R.RNLHandler_Process((y, c, c), (oy, ou, ov)) == R.RNLErrorBadParameter
+    assert R.RNLHandler_Deinit() == 0
+
+
+@pytest.mark.parametrize("passes,mode", [(1, 1), (2, 1), (2, 2)])
+def test_16bit_depth_against_the_oracle(tmp_path, passes, mode):
+    """bits=16 (Raisr.cpp:1462-1469: `_16` files, NF_16 Gaussian table, clamp 0..65535).  No `_16` model ships, so the
+    test synthesises the folder from the 10-bit files; u16 full-range frames through oracle and HIP, 1- and 2-pass."""
+    import shutil
+    import raisr_hip as R
+    import synth
+    src = folder("filters_2x/filters_highres")
+    dst = tmp_path / "filters_16"
+    dst.mkdir()
+    shutil.copy(f"{src}/config", dst / "config")
+    for stem in ("filterbin_2", "Qfactor_strbin_2", "Qfactor_cohbin_2"):
+        for sfx in ("", "_2"):
+            shutil.copy(f"{src}/{stem}_10{sfx}", dst / f"{stem}_16{sfx}")
+    w, h = 88, 56
+    rng = np.random.default_rng(16)
+    frames = {"random": rng.integers(0, 65536, (h, w)).astype(np.uint16),
+              "smooth": np.clip(synth.natural_y(w, h, 10, seed=3).astype(np.int64) * 64 + rng.integers(-300, 300, (h, w)), 0, 65535).astype(np.uint16)}
+    for nm, y in frames.items():
+        ref = oracle_y(y, ("x", str(dst), (2, 1), 16, passes, mode, 2, True))
+        assert ref.dtype == np.uint16 and int(ref.max()) > 1023, nm
+        dev = R.RaisrDevice(0)
+        try:
+            dev.set_model_from_folder(str(dst), 16, passes)
+            dev.configure(w, h, 2 * w, 2 * h, bits=16, full_range=True, passes=passes, mode=mode, hash_variant=R.HASH_AVX512)
+            out = np.zeros((2 * h, 2 * w), np.uint16)
+            dev.process_host(y, out)
+        finally:
+            dev.close()
+        bad = np.argwhere(out != ref)
+        assert bad.size == 0, (nm, len(bad), bad[:5].tolist())
+    # and through the plugin API (RNLInit's `_16` path names, full-range clamp)
+    c = np.full((h // 2, w // 2), 32768, np.uint16)
+    oy, _, _ = R.upscale_frame_host(frames["random"], c, c, str(dst), ratio=2.0, bits=16, range_type=R.FullRange, asm_type=R.AVX512,
+                                    passes=passes, mode=mode)
+    assert np.array_equal(oy, oracle_y(frames["random"], ("x", str(dst), (2, 1), 16, passes, mode, 2, True)))

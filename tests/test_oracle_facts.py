@@ -157,3 +157,35 @@ print(json.dumps(got))
     assert len(got) == 8
     for k, v in got.items():
         assert want[k] == v, k
+
+
+def test_avx512_build_of_the_oracle_gives_the_same_digests():
+    """bench.py's cpu_baseline uses the AVX-512 build of the oracle sources on hosts that execute it
+    (oracle/Makefile: libraisr_oracle_avx512.so); it must reproduce the committed digests bit for bit."""
+    import subprocess
+    import sys
+    import oracle_py as O
+    if not O._host_has_avx512():
+        pytest.skip("host does not execute AVX-512")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libraisr_oracle_avx512.so"])
+    code = r'''
+import hashlib, json, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, "video-super-resolution-library_amd")
+from common import CASES, oracle_y
+import synth, oracle_py
+got = {}
+for case in CASES:
+    for nm, fr in (("natural", synth.natural_y(96, 64, case[3], seed=4242)), ("random", synth.random_y(96, 64, case[3], seed=99))):
+        got[f"{case[0]}/{nm}"] = hashlib.sha256(oracle_y(fr, case).tobytes()).hexdigest()
+assert "AVX-512" in oracle_py.isa(), oracle_py.isa()
+print(json.dumps(got))
+'''
+    env = dict(os.environ, RAISR_ORACLE_ISA="avx512")
+    env.pop("RAISR_ORACLE_SO", None)
+    run = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = json.loads(run.stdout.strip().splitlines()[-1])
+    want = json.load(open(os.path.join(ROOT, "tests/golden/oracle_digests.json")))
+    assert len(got) == 2 * len(CASES)
+    for k, v in got.items():
+        assert want[k] == v, k

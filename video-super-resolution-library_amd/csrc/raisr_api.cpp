@@ -50,6 +50,9 @@ struct State {
     std::vector<raisr_hip_ctx *> extra;           // contexts of bands 1..K-1
     std::vector<raisr_hip_band> yBands, cBands;   // luma / chroma plans (same count; cBands empty = chroma on band 0)
     int chromaInH = 0, chromaOutH = 0;
+    // plane geometry RNLSetRes configured: RNLProcess refuses frames that differ (the copies are asynchronous DMAs)
+    unsigned geo[6][2] = {};                      // {width, height} of inY, inCr, inCb, outY, outCr, outCb
+    bool deviceChosen = false;                    // RNLSetOpenCLContext named a device; otherwise RAISR_HIP_DEVICE / 0
 } G;
 
 // ---- config / trained-data parsing -------------------------------------------------------------
@@ -211,6 +214,14 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
     std::cout << "-------------------------------------------\n";
     (void)threadCount;   // accepted and ignored: the GPU grid replaces the CPU row bands
 
+    // A re-initialisation starts from scratch: whatever an earlier RNLInit left behind (device context, geometry,
+    // models) must not survive a failure below and run with the new, mismatched parameters.
+    dropContext();
+    G.inited = false;
+    if (!G.deviceChosen) {                       // unmodified vf_raisr only names a device for asm=opencl
+        if (const char *e = std::getenv("RAISR_HIP_DEVICE")) { const int d = std::atoi(e); G.device = d < 0 ? 0 : d; }
+    }
+
     G.passes = 1; G.twoPassMode = 1;
     if (passes == 2) {
         G.passes = passes;
@@ -330,8 +341,11 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
 RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *inCb,
                        VideoDataType *outY, VideoDataType *outCr, VideoDataType *outCb)
 {
-    (void)inCb; (void)outCb;
     if (!G.inited || !G.ctx || !inY || !outY) return RNLErrorBadParameter;
+    {
+        VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
+        for (int i = 0; i < 6; i++) { G.geo[i][0] = pl[i] ? pl[i]->width : 0; G.geo[i][1] = pl[i] ? pl[i]->height : 0; }
+    }
     raisr_hip_config cfg{};
     cfg.in_width = (int)inY->width; cfg.in_height = (int)inY->height;
     cfg.out_width = (int)outY->width; cfg.out_height = (int)outY->height;
@@ -392,6 +406,16 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
     if (!inCb || !inCb->pData || !outCb || !outCb->pData) return RNLErrorBadParameter;
     if (!G.inited || !G.resSet || !G.ctx) return RNLErrorBadParameter;
     if (blendingMode != CountOfBitsChanged && blendingMode != Randomness) return RNLErrorBadParameter;
+    {   // the frame must have the geometry RNLSetRes sized the device planes for, and rows at least one line long
+        VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
+        const unsigned bps = G.bitDepth == 8 ? 1u : 2u;
+        for (int i = 0; i < 6; i++) {
+            if (i == 2 || i == 5) {            // RNLSetRes never looked at the Cb planes: they must match Cr
+                if (pl[i]->width != pl[i - 1]->width || pl[i]->height != pl[i - 1]->height) return RNLErrorBadParameter;
+            } else if (pl[i]->width != G.geo[i][0] || pl[i]->height != G.geo[i][1]) return RNLErrorBadParameter;
+            if ((uint64_t)pl[i]->step < (uint64_t)pl[i]->width * bps) return RNLErrorBadParameter;
+        }
+    }
     auto failed = [&]() {
         std::cout << "[RAISR ERROR] process failed: " << raisr_hip_last_error() << std::endl;
         return RNLErrorUndefined;
@@ -448,6 +472,7 @@ RNLERRORTYPE RNLSetOpenCLContext(void *context, void *deviceID, int platformInde
 {
     (void)context; (void)deviceID; (void)platformIndex;
     G.device = deviceIndex < 0 ? 0 : deviceIndex;     // HIP device ordinal (vf_raisr `device=` option)
+    G.deviceChosen = true;
     return RNLErrorNone;
 }
 

@@ -1045,8 +1045,7 @@ struct raisr_hip_ctx {
     void* d_mid = nullptr;                      // two-pass intermediate (sample type), only when the passes differ in size
     int passW[2] = {0, 0}, passH[2] = {0, 0};
     GaussW gauss{};
-    // host staging for raisr_hip_process_host
-    void* h_pin = nullptr; size_t h_pin_bytes = 0;
+    // device staging for raisr_hip_process_host
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
     KernelTimer timer;
 };
@@ -1364,7 +1363,6 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
-    if (c->h_pin) (void)hipHostFree(c->h_pin);
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
     pool_put_stream(c->device, c->stream);
     pool_put_stream(c->device, c->stream2);
@@ -1413,6 +1411,7 @@ int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, 
 int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void* device_blob, size_t bytes, void* stream)
 {
     if (!c || !device_blob || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (bytes < (size_t)kBlobHeader) return fail(RAISR_HIP_EINVAL, "model blob shorter than its header");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     BlobHeader h{};
@@ -1455,6 +1454,8 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     if (cfg->passes != 1 && cfg->passes != 2) return fail(RAISR_HIP_EINVAL, "passes must be 1 or 2");
     if (cfg->in_width <= 0 || cfg->in_height <= 0 || cfg->out_width <= 0 || cfg->out_height <= 0)
         return fail(RAISR_HIP_EINVAL, "bad plane size");
+    if ((uint64_t)cfg->out_width * (uint64_t)cfg->out_height >= (1ull << 31) || (uint64_t)cfg->in_width * (uint64_t)cfg->in_height >= (1ull << 31))
+        return fail(RAISR_HIP_EINVAL, "planes of 2^31 samples or more are not supported (32-bit element offsets)");
     if (cfg->clamp_lo < 0 || cfg->clamp_hi <= cfg->clamp_lo || cfg->clamp_hi >= (1 << cfg->bits))
         return fail(RAISR_HIP_EINVAL, "clamp range must satisfy 0 <= lo < hi < 2^bits");
     if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512 &&
