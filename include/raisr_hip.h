@@ -159,6 +159,15 @@ int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
  * production kernel keeps the hashes on chip. */
 int raisr_hip_debug_keep_stages(raisr_hip_ctx *ctx, int on);
 int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash_out, float *hr_out);
+/* Certified hash stage (the production kernel of the fp32 numerics computes the structure tensor approximately and
+ * sends only the pixels whose bucket it cannot certify through the reference's exact instruction sequence).
+ *   collect != 0: count, over the frames processed from now on, {pixels sent to the exact path, certified buckets that
+ *                 differed from the exact ones (only counted with check != 0; must stay 0), filtered pixels};
+ *   check   != 0: self-check mode -- EVERY pixel also takes the exact path and certified buckets are compared with it.
+ * raisr_hip_debug_certify_stats() synchronises the context's stream and reads the three counters.
+ * Replaces nothing in the reference; it is the observability of an optimisation the reference does not have. */
+int raisr_hip_debug_certify(raisr_hip_ctx *ctx, int collect, int check);
+int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[3]);
 /* Hash bucket (0..215) of `n` host-side structure-tensor triples (a, b, d) x n with pass `pass_index`'s
  * thresholds, computed by the very device functions the hash kernel runs (fast path plus generic fall-back
  * for RAISR_HIP_HASH_AVX512; the RCPPS/RSQRTPS flavour for RAISR_HIP_HASH_AVX2).  Replaces nothing in the

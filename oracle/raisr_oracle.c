@@ -459,3 +459,19 @@ void ora_hash_array(const float *abd, size_t n, const ora_pass_t *P, int avx2_va
 {
     for (size_t i = 0; i < n; i++) out[i] = (uint8_t)hash_pixel(abd[3 * i], abd[3 * i + 1], abd[3 * i + 2], P, avx2_variant);
 }
+
+/* Introspection for tests: the exact structure tensor (a, b, d) of every pixel of the filtered rows/columns
+ * [LM, H-LM) x [LM, W-LM) of an integer LR plane, exactly as ora_pass computes it (gtwg_row).  Planes a, b, d are
+ * W x H floats; pixels outside the zone are left untouched. */
+void ora_tensor_plane(const uint16_t *lr, int W, int H, int bits, float *a, float *b, float *d)
+{
+    float wg[PATCH][PATCH];
+    ora_gaussian_weights(bits, wg);
+    size_t n = (size_t)W * H;
+    float *L = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++) L[i] = (float)lr[i];
+    #pragma omp parallel for schedule(dynamic, 2)
+    for (int r = LM; r < H - LM; r++)
+        if (W > 2 * LM) gtwg_row(L, W, r, LM, W - LM, wg, a + (size_t)r * W, b + (size_t)r * W, d + (size_t)r * W);
+    free(L);
+}

@@ -1,0 +1,87 @@
+"""-m gpu: the certified hash stage (k_hashfilter_ac).  The kernel computes the structure tensor approximately and keeps a
+bucket only when rigorous bounds certify it; everything else takes the reference's exact instruction sequence.  Here:
+self-check mode (every pixel ALSO takes the exact path; a certified bucket that differs is counted -- must be 0), output
+bit-exact against the oracle, and the fraction of pixels that needed the exact path, per frame kind and flavour."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import folder, oracle_y, dtype_for
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _frames(w, h, bits):
+    import synth
+    maxv = (1 << bits) - 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.clip(maxv * (0.25 + 0.0008 * xx + 0.0004 * yy + 0.08 * np.sin(xx / 17.0) * np.cos(yy / 23.0)), 0, maxv)
+    edges = np.full((h, w), maxv * 40 // 255); edges[:, w // 3:] = maxv * 200 // 255; edges[h // 2:, :] //= 2
+    edges[h // 4:h // 3, :] = maxv * 90 // 255
+    dt = dtype_for(bits)
+    return {"natural": synth.natural_y(w, h, bits, seed=12345), "random": synth.random_y(w, h, bits, seed=777),
+            "checker": synth.checker_y(w, h, bits), "constant": synth.constant_y(w, h, bits),
+            "smooth": smooth.astype(dt), "edges": edges.astype(dt)}
+
+
+CASES = [  # (id, folder, ratio, bits, passes, mode, asm, full)
+    ("2x_8b_avx512", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False),
+    ("2x_8b_avx2", "filters_2x/filters_lowres", (2, 1), 8, 1, 1, 1, False),
+    ("2x_10b_2p", "filters_2x/filters_highres", (2, 1), 10, 2, 1, 2, True),
+    ("1.5x_8b_2p_m2", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 2, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_certified_buckets_equal_exact_buckets(case):
+    import raisr_hip as R
+    cid, fold, (rn, rd), bits, passes, mode, asm, full = case
+    w, h = 372, 214                      # not a multiple of any tile size; several tiles in both directions
+    ow, oh = w * rn // rd, h * rn // rd
+    report = {}
+    for kind, y in _frames(w, h, bits).items():
+        ref = oracle_y(y, case)
+        for check in (True, False):      # self-check mode (all pixels through both paths), then production mode
+            dev = R.RaisrDevice(0)
+            try:
+                dev.set_model_from_folder(folder(fold), bits, passes)
+                dev.configure(w, h, ow, oh, bits=bits, full_range=full, passes=passes, mode=mode, hash_variant=asm)
+                dev.certify_debug(True, check)
+                out = np.zeros((oh, ow), dtype_for(bits))
+                dev.process_host(np.ascontiguousarray(y), out)
+                st = dev.certify_stats()
+            finally:
+                dev.close()
+            assert st["pixels"] > 0, (cid, kind)
+            assert st["mismatches"] == 0, (cid, kind, st)
+            bad = np.argwhere(out != ref)
+            assert bad.size == 0, (cid, kind, check, len(bad), bad[:5].tolist())
+        report[kind] = round(st["uncertain"] / st["pixels"], 5)
+    print("fallback fraction", cid, json.dumps(report))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"certify_fallback_{cid}.json"), "w") as f:
+        json.dump(report, f)
+    assert report["natural"] < 0.05 and report["constant"] == 0.0
+
+
+def test_exact_kernel_still_selectable(monkeypatch):
+    """RAISR_HIP_CERTIFY=0 keeps the all-exact kernel (A/B switch): same bits."""
+    import raisr_hip as R
+    import synth
+    monkeypatch.setenv("RAISR_HIP_CERTIFY", "0")
+    case = CASES[0]
+    y = synth.natural_y(200, 120, 8, seed=5)
+    dev = R.RaisrDevice(0)
+    try:
+        dev.set_model_from_folder(folder(case[1]), 8, 1)
+        dev.configure(200, 120, 400, 240, bits=8, passes=1, hash_variant=2)
+        out = np.zeros((240, 400), np.uint8)
+        dev.process_host(y, out)
+        with pytest.raises(RuntimeError):
+            dev.certify_stats()
+    finally:
+        dev.close()
+    assert np.array_equal(out, oracle_y(y, case))

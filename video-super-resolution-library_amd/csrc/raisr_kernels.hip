@@ -39,6 +39,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -86,6 +87,9 @@ struct PassParams {
     const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
     const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
     int write_hash;              // fused kernel: also write the hash plane (introspection for tests)
+    unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels} or null
+    int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
+    int ai_bzero;                // angle bucket the reference's hash gives when b == 0 (xx = 1): a constant of the model's qangle
 };
 
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
@@ -590,6 +594,248 @@ __global__ __launch_bounds__(256) void k_debug_hash(const float* __restrict__ ab
     out[i] = (uint8_t)h;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Certified hashing ("approximate, then certify").  The output needs the exact BUCKET, not the exact
+// tensor.  k_hashfilter_ac therefore computes the structure tensor cheaply -- the literal 11 x 11 table is a rank-1
+// table up to its 6-digit truncation, so a separable 11 + 11-tap pass over the per-pixel gradient products
+// (gx^2, gx gy, gy^2) reproduces (a, b, d) to a relative eps of a few 1e-6 -- evaluates the hash quantities in plain
+// fp32 (native sqrt / rcp), and accepts the bucket only when rigorous bounds on
+//     |quantity the reference's instruction sequence produces  -  quantity computed here|
+// keep angle*24/pi, strength and coherence away from every bucket boundary and every discontinuity of the
+// reference's code (sign of b, xx, L2, the "ang < 0" wrap).  Everything else -- a few per cent of the pixels on
+// noisy content, 1-D structures and exactly symmetric patterns on synthetic content -- goes through a per-tile
+// worklist to the exact code (exact_pixel below: the same operations in the same order as hash_phase).
+// The bounds (tests/tools/certify_proto.py derives and validates them against the oracle):
+//   tensor      |a-a'| <= eps a', |d-d'| <= eps d', |b-b'| <= eps T'/2,  T' = a'+d'
+//               eps = 1.05 (eps_w + 48 u): eps_w = max |us_i us_k / w_ik - 1| over the ACTUAL fp32 constants of both paths,
+//               16 u for the reference's 12-term fma chains + 4-level fold, 23 u for the separable passes (u = 2^-24).
+//   root        reference: rad = fl(T^2/4 - (ad - b^2)) = R + eta, R = ((a-d)/2)^2 + b^2, |eta| <= 2 u T^2;  s = sqrt14(rad),
+//               sqrt14(x) = sqrt(x)(1 + e), |e| <= E (1.0e-4 for VRCP14(VRSQRT14), 6.5e-4 for RCPPS(RSQRTPS); enumerated in
+//               tests/test_certify_bounds.py).  With s* = sqrt(R'):   |s - s*| <= E_s = 1.42 eps T' + (2e-7 + eps^2) T'^2 / s* + 1.05 E s*
+//   L1, L2, xx  |. - .*| <= E_L = E_s + (eps/2 + 6 u) T'   (L2* = (a'd' - b'^2) / L1* carries 4 u T' more)
+//   coherence   t = sqrt(L2/L1): |coh - coh*| <= 2 t* (0.55 (E_L2/(L2*-E_L2) + E_L/(L1*-E_L)) + 2.4 E) + 2e-6, needs L2* > 2 E_L2
+//   angle       rr = (xx - ay)/(xx + ay), |d rr| <= 2((ay+E_ay) E_L + (xx+E_L) E_ay) / (xx + ay - E_L - E_ay)^2 + 4 u,
+//               |P'(rr)| < 1 for the cubic P  =>  |ang_raw - ang_raw*| <= d rr + 1.5e-6;  q = ang 24/pi: + 2e-5
+// ------------------------------------------------------------------------------------------------
+struct SepW {
+    float us[11];                // separable weights, sqrt(NF) folded in: us[i] us[k] ~ wT[k][i]
+    float es1, es2;              // 1.42 eps, 2e-7 + eps^2
+    float eEL, eEb;              // eps/2 + 6 u, eps/2
+    float e105[2], e24[2];       // 1.05 E and 2.4 E for the AVX-512 (0) and the AVX2 (1) approximation instructions
+};
+
+struct HashQf { float qangle, qs0, qs1, qc0, qc1; };
+
+// returns true when the bucket is certified
+__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, int ai_bzero, unsigned& bucket)
+{
+    const float U1 = 5.9604645e-8f;                      // 2^-24
+    const float pi = 3.141592653f;
+    const float ONEQTR_PI = (float)(3.14159265358979323846 / 4.0);
+    const float T = a + d;
+    const float m = 0.5f * (a - d);
+    const float bb = b * b;
+    const float R = __builtin_fmaf(m, m, bb);
+    const float s = __builtin_amdgcn_sqrtf(R);
+    const float hT = 0.5f * T;
+    const float L1 = hT + s;
+    const float rL1 = __builtin_amdgcn_rcpf(L1);
+    const float det = __builtin_fmaf(a, d, -bb);
+    const float L2 = det * rL1;                          // = T/2 - s without the cancellation
+    const float rs = __builtin_amdgcn_rcpf(s);
+    const float E_s = __builtin_fmaf(S.es1, T, __builtin_fmaf((S.es2 * T) * T, rs, S.e105[fl] * s));
+    bool ok = (T > 0.0f) & (s > 0.0f) & (E_s <= 0.25f * s);
+    const float E_L = __builtin_fmaf(S.eEL, T, E_s);
+    const float E_L2 = __builtin_fmaf(4.0f * U1, T, E_L);
+    // strength
+    ok &= (__builtin_fabsf(L1 - Q.qs0) > E_L) & (__builtin_fabsf(L1 - Q.qs1) > E_L);
+    const int si = (int)(Q.qs0 <= L1) + (int)(Q.qs1 <= L1);
+    // coherence
+    ok &= L2 > 2.0f * E_L2;
+    const float t = __builtin_amdgcn_sqrtf(L2 * rL1);
+    const float coh = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    const float dcoh = __builtin_fmaf(2.0f * t, __builtin_fmaf(0.55f, __builtin_fmaf(E_L2, __builtin_amdgcn_rcpf(L2 - E_L2), E_L * __builtin_amdgcn_rcpf(L1 - E_L)), S.e24[fl]), 2e-6f);
+    ok &= (__builtin_fabsf(coh - Q.qc0) > dcoh) & (__builtin_fabsf(coh - Q.qc1) > dcoh);
+    const int ci = (int)(Q.qc0 <= coh) + (int)(Q.qc1 <= coh);
+    // angle
+    const float E_b = S.eEb * T;
+    const float ab = __builtin_fabsf(b);
+    const float ay = ab + 1e-10f;
+    const float xx = m >= 0.0f ? m + s : bb * __builtin_amdgcn_rcpf(s - m);        // (s - m)(s + m) = b^2
+    const float E_ay = __builtin_fmaf(U1, ay, E_b);
+    const float xpa = xx + ay;
+    const float D = xpa - (E_L + E_ay);
+    const float rr = (xx - ay) * __builtin_amdgcn_rcpf(xpa);
+    const float rD = __builtin_amdgcn_rcpf(D);
+    const float drr = __builtin_fmaf(2.0f * __builtin_fmaf(ay + E_ay, E_L, (xx + E_L) * E_ay), rD * rD, 4.0f * U1);
+    const float ang_raw = __builtin_fmaf(__builtin_fmaf(0.1963f * rr, rr, -0.9817f), rr, ONEQTR_PI);
+    const float dang = drr + 1.5e-6f;
+    float ang = b < 0.0f ? -ang_raw : ang_raw;
+    ang = ang < 0.0f ? ang + pi : ang;
+    const float q = ang * Q.qangle;
+    const float dq = __builtin_fmaf(Q.qangle, dang, 2e-5f);
+    const float k = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(q), 0.0f), 23.0f);
+    const float fr = q - k;
+    const bool c_ang = (xx > 2.0f * E_L) & (D > 0.0f) & (ab > E_b) & (__builtin_fabsf(ang_raw) > dang) &
+                       ((k < 1.0f) | (fr > dq)) & ((k > 22.0f) | (1.0f - fr > dq));
+    const bool bzero = (a == 0.0f) | (d == 0.0f);        // all gx (or all gy) of the window are 0: the reference's b is exactly 0
+    ok &= bzero | c_ang;
+    const int ai = bzero ? ai_bzero : (int)k;
+    bucket = (unsigned)(ai * 9 + si * 3 + ci);
+    return ok;
+}
+
+// The reference's arithmetic for ONE pixel (lane-private): window origin (prow, pcol) in the gradient tile.  Same
+// operations in the same order as hash_phase (column accumulators over the 11 patch rows, sumitup_ps_512 fold), then
+// the flavour logic of hash_phase's epilogue.
+__device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& gw, const f2* sG, const uint2* sTab,
+                                                      int prow, int pcol, int c, unsigned& hA, unsigned& hB)
+{
+    constexpr int GW_ = 74;
+    const f2* base = sG + prow * GW_ + pcol;
+    f2 curAD = {0.f, 0.f}, holdAD = {0.f, 0.f}, t1AD = {0.f, 0.f};
+    float curB = 0.f, holdB = 0.f, t1B = 0.f;
+#pragma unroll 1
+    for (int kk = 0; kk < 11; kk++) {
+        const int k = c_col_order[kk];
+        f2 AD = {0.f, 0.f};
+        float B = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float wv = gw.wT[k][i];
+            const f2 w2 = {wv, wv};
+            const f2 gg = base[i * GW_ + k];
+            const f2 pq = gg * w2;
+            AD = __builtin_elementwise_fma(pq, gg, AD);
+            B = __builtin_fmaf(pq.x, gg.y, B);
+        }
+        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
+        if (start) { curAD = AD; curB = B; }
+        else { curAD = curAD + AD; curB = curB + B; }
+        if (kk == 2 || kk == 8) { holdAD = curAD; holdB = curB; }
+        if (kk == 5) { t1AD = holdAD + curAD; t1B = holdB + curB; }
+    }
+    const f2 ad = (holdAD + curAD) + t1AD;
+    const float bb = (holdB + curB) + t1B;
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    hA = 0xFFu; hB = 0xFFu;
+    unsigned h = 0xFFu;
+    if (inA) {
+        bool rare = false;
+        h = (unsigned)hash_px_impl<0>(ad.x, bb, ad.y, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px_generic(ad.x, bb, ad.y, HQ, sTab);
+    }
+    if (inB) {
+        const unsigned hL = (unsigned)hash_px_legacy(ad.x, bb, ad.y, HQ, sTab);
+        if (inA) hB = hL; else h = hL;
+    }
+    hA = (inA || inB) ? h : 0xFFu;
+}
+
+// hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
+// (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
+template <int LW>
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const f2* sG, float4* sV,
+                                              const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
+                                              int c0, int r0)
+{
+    constexpr int GW_ = 74, TW = 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // ---- V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4) ----
+    auto vpass = [&](int x, int rg) {
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 14; t++) {
+            const f2 g = sG[(4 * rg + t) * GW_ + x];
+            const float pa = g.x * g.x, pb = g.x * g.y, pd = g.y * g.y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = t - r;
+                if (i >= 0 && i < 11) {
+                    va[r] = __builtin_fmaf(S.us[i], pa, va[r]);
+                    vb[r] = __builtin_fmaf(S.us[i], pb, vb[r]);
+                    vd[r] = __builtin_fmaf(S.us[i], pd, vd[r]);
+                }
+            }
+        }
+        sV[(0 * 4 + rg) * GW_ + x] = make_float4(va[0], va[1], va[2], va[3]);
+        sV[(1 * 4 + rg) * GW_ + x] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        sV[(2 * 4 + rg) * GW_ + x] = make_float4(vd[0], vd[1], vd[2], vd[3]);
+    };
+    vpass(lane, w);
+    if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
+    if (threadIdx.x == 0) sCnt[0] = 0;
+    __syncthreads();
+
+    // ---- H pass: lane = column, wave w = row group ----
+    float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f}, td[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const float4 xa = sV[(0 * 4 + w) * GW_ + lane + k];
+        const float4 xb = sV[(1 * 4 + w) * GW_ + lane + k];
+        const float4 xd = sV[(2 * 4 + w) * GW_ + lane + k];
+        const float uk = S.us[k];
+        ta[0] = __builtin_fmaf(uk, xa.x, ta[0]); ta[1] = __builtin_fmaf(uk, xa.y, ta[1]); ta[2] = __builtin_fmaf(uk, xa.z, ta[2]); ta[3] = __builtin_fmaf(uk, xa.w, ta[3]);
+        tb[0] = __builtin_fmaf(uk, xb.x, tb[0]); tb[1] = __builtin_fmaf(uk, xb.y, tb[1]); tb[2] = __builtin_fmaf(uk, xb.z, tb[2]); tb[3] = __builtin_fmaf(uk, xb.w, tb[3]);
+        td[0] = __builtin_fmaf(uk, xd.x, td[0]); td[1] = __builtin_fmaf(uk, xd.y, td[1]); td[2] = __builtin_fmaf(uk, xd.z, td[2]); td[3] = __builtin_fmaf(uk, xd.w, td[3]);
+    }
+
+    // ---- approximate hash + certification of the lane's 4 pixels ----
+    const int c = c0 + lane;
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    const int fl = inB ? 1 : 0;                            // the AVX2 flavour's wider table error covers the re-hashed columns too
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    const int ai_bzero = P.ai_bzero;                    // angle bucket of b == 0 (xx = 1, ay = 1e-10), evaluated on the host
+    unsigned nUnc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int prow = 4 * w + j;
+        const int r = r0 + prow;
+        const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
+        unsigned bucket;
+        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, ai_bzero, bucket);
+        const bool zero = (ta[j] + td[j]) == 0.0f;          // flat window: the reference's tensor is exactly (0, 0, 0) as well
+        cert |= zero;
+        // first hash: AVX-512 flavour where the column has one, else the AVX2 flavour; second hash: AVX2 flavour of the
+        // re-hashed columns.  A certified bucket holds for both flavours (fl selects the wider table error there); the
+        // zero tensor's bucket is looked up per flavour (computed once per tile with the exact code).
+        const unsigned bA = zero ? sList[1024 + (inA ? 0 : 1)] : bucket;
+        const unsigned bB = zero ? sList[1025] : bucket;
+        const bool unc = zone && (!cert || P.cert_check);
+        sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
+        sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
+        if (unc) {
+            const unsigned slot = atomicAdd(sCnt, 1u);
+            sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
+        }
+        nUnc += (zone && !cert) ? 1u : 0u;
+    }
+    if (P.cert_stats) {
+        if (nUnc) atomicAdd(&sCnt[1], nUnc);
+    }
+    __syncthreads();
+
+    // ---- worklist: the exact path for what could not be certified; <= 64 entries per wave and round ----
+    const unsigned n = sCnt[0];
+    unsigned bad = 0;
+    for (unsigned base = 64u * w; base < n; base += 256u) {
+        const unsigned e = base + lane;
+        if (e < n) {
+            const unsigned ent = sList[e];
+            const int prow = (ent >> 6) & 15, pcol = ent & 63;
+            unsigned hA, hB;
+            exact_pixel(P, gw, sG, sTab, prow, pcol, c0 + pcol, hA, hB);
+            if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
+            sH[prow * TW + pcol] = (uint8_t)hA;
+            sH2[prow * TW + pcol] = (uint8_t)hB;
+        }
+    }
+    if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
+    if (n) __syncthreads();                                // (n is the same in every thread)
+}
+
 #include "raisr_fp16_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -777,6 +1023,77 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
         if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
     }
     __builtin_amdgcn_wave_barrier();                         // LDS is in order within a wave; keep the compiler from reordering
+    filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
+}
+
+
+// k_hashfilter_ac: k_hashfilter with the certified hash stage (hash_phase_ac) -- the production kernel of the fp32
+// numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
+// pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
+template <typename T>
+__global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[GH * GW_];
+    __shared__ float4 sV[3 * 4 * GW_];
+    __shared__ uint2 sTab[128];
+    __shared__ uint8_t sH[TH * TW];
+    __shared__ uint8_t sH2[TH * TW];
+    __shared__ uint16_t sList[1024 + 2];      // worklist entries; [1024], [1025]: bucket of the zero tensor per flavour
+    __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
+            const unsigned idx = threadIdx.x + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
+        if (threadIdx.x < 2) {                 // bucket of the all-zero tensor in both flavours (flat windows)
+            const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+            sList[1024 + threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? hash_px_generic(0.f, 0.f, 0.f, HQ, sTab)
+                                                                    : hash_px_legacy(0.f, 0.f, 0.f, HQ, sTab));
+        }
+    }
+    __syncthreads();
+    hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0);
+    if (P.write_hash) {
+        const int c = c0 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = r0 + 4 * w + j;
+            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
+        }
+    }
+    if (P.cert_stats && threadIdx.x == 0) {
+        const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
+        if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
+        if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
+        atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
+    }
     filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
 }
 
@@ -1000,6 +1317,30 @@ GaussW make_gauss(int bits)
     return g;
 }
 
+// Separable weights and error constants of the certified hash stage (see the comment above approx_hash).
+// us_i = sqrt(NF * literal_ii): the literal table is the outer product of a 1-D Gaussian up to its 6-digit truncation.
+// eps_w is measured on the very fp32 constants the two paths use, so it is a bound, not an estimate.
+SepW make_sep(const GaussW& g)
+{
+    SepW S{};
+    for (int i = 0; i < 11; i++) S.us[i] = (float)sqrt((double)g.wT[i][i]);
+    double eps_w = 0.0;
+    for (int i = 0; i < 11; i++)
+        for (int k = 0; k < 11; k++) {
+            const double r = (double)S.us[i] * (double)S.us[k] / (double)g.wT[k][i] - 1.0;
+            if (fabs(r) > eps_w) eps_w = fabs(r);
+        }
+    const double u = 5.9604644775390625e-8;                     // 2^-24
+    const double eps = 1.05 * (eps_w + 48.0 * u);
+    const double E[2] = {1.0e-4, 6.5e-4};                       // sup |sqrt14(x)/sqrt(x) - 1|: VRCP14(VRSQRT14), RCPPS(RSQRTPS)
+    S.es1 = (float)(1.42 * eps);
+    S.es2 = (float)(2e-7 + eps * eps);
+    S.eEL = (float)(0.5 * eps + 6.0 * u);
+    S.eEb = (float)(0.5 * eps);
+    for (int f = 0; f < 2; f++) { S.e105[f] = (float)(1.05 * E[f]); S.e24[f] = (float)(2.4 * E[f]); }
+    return S;
+}
+
 // Column plan of the reference's chunk driver (Raisr.cpp:1065-1066,1246-1250).
 void column_plan(int W, int hash_variant, PassParams& P)
 {
@@ -1027,6 +1368,10 @@ struct raisr_hip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // chroma lane of raisr_hip_process_host (overlaps the Y path)
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    bool certify = true;                       // certified hash stage (k_hashfilter_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernel
+    int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
+    unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
+    SepW sep{};
     int keep_hash_plane = 0;                   // fused kernel also writes the hash plane (set by raisr_hip_debug_read_stage users)
     raisr_hip_config cfg{};
     int blending = RAISR_HIP_BLEND_COUNT;      // per-call BlendingMode (RNLProcess argument)
@@ -1120,6 +1465,16 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
     P.tab14 = c->d_tab14;
     P.lut_legacy = c->d_lut;
+    {   // b == 0 in the reference's hash (Raisr_AVX512.cpp:151-173,204-233): xx = 1, ay = |0| + 1e-10, same fp32 operations
+        volatile float one = 1.0f, tiny = 1e-10f;
+        const float x1 = one, ay = 0.0f + tiny;
+        const float rr = (x1 - ay) / (x1 + ay);
+        float ang = fmaf(fmaf(0.1963f * rr, rr, -0.9817f), rr, (float)(3.14159265358979323846 / 4.0));
+        ang = ang + ((ang < 0.0f) ? 3.141592653f : 0.0f);
+        const float fl = floorf(ang * P.qangle);
+        const int ai = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
+        P.ai_bzero = ai < 0 ? 0 : (ai > 23 ? 23 : ai);
+    }
     return P;
 }
 
@@ -1135,7 +1490,14 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
-        if (c->fused) {
+        if (c->fused && c->certify) {
+            P.write_hash = c->keep_hash_plane;
+            P.cert_stats = c->d_cert_stats;
+            P.cert_check = c->cert_check;
+            timer_begin(c, "k_hashfilter_ac", s, slot);
+            hipLaunchKernelGGL((k_hashfilter_ac<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
             timer_begin(c, "k_hashfilter", s, slot);
             if (!avx2all)
@@ -1307,6 +1669,7 @@ static void pool_put_stage(int device, void* p, size_t bytes)
 static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
+    if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
     int rc = pool_get_stream(c->device, &c->stream);
     if (rc) return rc;
     rc = pool_get_stream(c->device, &c->stream2);
@@ -1363,6 +1726,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
+    if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
     pool_put_stream(c->device, c->stream);
     pool_put_stream(c->device, c->stream2);
@@ -1474,6 +1838,7 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     free_scratch(c);
     c->cfg = *cfg;
     c->gauss = make_gauss(cfg->bits);
+    c->sep = make_sep(c->gauss);
     const bool mode2 = cfg->passes == 2 && cfg->two_pass_mode == 2;
     c->passW[0] = mode2 ? cfg->in_width : cfg->out_width;
     c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
@@ -1727,6 +2092,29 @@ int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint8_t* hash_o
     const size_t n = (size_t)c->passW[pass_index] * c->passH[pass_index];
     if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n, hipMemcpyDeviceToHost));
     if (hr_out) HIP_TRY(hipMemcpy(hr_out, c->d_hr[pass_index], n * sizeof(float), hipMemcpyDeviceToHost));
+    return RAISR_HIP_OK;
+}
+
+// Certified hash stage: statistics and self-check (see include/raisr_hip.h).
+int raisr_hip_debug_certify(raisr_hip_ctx* c, int collect, int check)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (collect && !c->d_cert_stats) HIP_TRY(hipMalloc((void**)&c->d_cert_stats, 3 * sizeof(unsigned)));
+    if (c->d_cert_stats) HIP_TRY(hipMemset(c->d_cert_stats, 0, 3 * sizeof(unsigned)));
+    if (!collect && c->d_cert_stats) { (void)hipFree(c->d_cert_stats); c->d_cert_stats = nullptr; }
+    c->cert_check = check != 0;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_certify_stats(raisr_hip_ctx* c, unsigned out[3])
+{
+    if (!c || !out) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (!c->d_cert_stats) return fail(RAISR_HIP_ESTATE, "statistics are not being collected");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_cert_stats, 3 * sizeof(unsigned), hipMemcpyDeviceToHost));
     return RAISR_HIP_OK;
 }
 

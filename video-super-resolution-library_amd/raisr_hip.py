@@ -104,6 +104,8 @@ def lib():
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.RNLHandler_Init.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
@@ -322,6 +324,16 @@ class RaisrDevice:
         out = np.zeros(abd.shape[0], np.uint8)
         _check(lib().raisr_hip_debug_hash(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
         return out
+
+    def certify_debug(self, collect=True, check=False):
+        """Certified hash stage: start (and zero) / stop the statistics; check=True also runs the exact path for every pixel."""
+        _check(lib().raisr_hip_debug_certify(self._h, int(collect), int(check)), "debug_certify")
+
+    def certify_stats(self):
+        """dict(uncertain, mismatches, pixels) accumulated since certify_debug(True, ...)."""
+        out = (ctypes.c_uint * 3)()
+        _check(lib().raisr_hip_debug_certify_stats(self._h, out), "debug_certify_stats")
+        return {"uncertain": int(out[0]), "mismatches": int(out[1]), "pixels": int(out[2])}
 
     def timing_enable(self, on=True):
         _check(lib().raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
