@@ -90,7 +90,20 @@ struct PassParams {
     unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels} or null
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int ai_bzero;                // angle bucket the reference's hash gives when b == 0 (xx = 1): a constant of the model's qangle
+    int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
+    const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
+    unsigned long long* prof;    // profiling aid: shader-clock cycles per phase of the certified hash stage, summed over tiles (or null)
 };
+
+// phase stamps of wave 0 / lane 0 (only when P.prof is set: RAISR_HIP_PHASES=1)
+#define RAISR_STAMP(P, slot, t_prev)                                                             \
+    do {                                                                                         \
+        if ((P).prof && threadIdx.x == 0) {                                                      \
+            const unsigned long long _t = clock64();                                             \
+            atomicAdd(&(P).prof[slot], _t - (t_prev));                                           \
+            (t_prev) = _t;                                                                       \
+        }                                                                                        \
+    } while (0)
 
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
 // each XCD has a private 4 MiB L2, so with the plain (blockIdx.x, blockIdx.y) order the eight tiles around
@@ -686,6 +699,25 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     return ok;
 }
 
+// first / second hash of a pixel in column c from its exact tensor: the flavour logic of hash_phase's epilogue
+__device__ __forceinline__ void flavour_hash(const PassParams& P, const uint2* sTab, float a, float b, float d, int c, unsigned& hA, unsigned& hB)
+{
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    hA = 0xFFu; hB = 0xFFu;
+    unsigned h = 0xFFu;
+    if (inA) {
+        bool rare = false;
+        h = (unsigned)hash_px_impl<0>(a, b, d, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px_generic(a, b, d, HQ, sTab);
+    }
+    if (inB) {
+        const unsigned hL = (unsigned)hash_px_legacy(a, b, d, HQ, sTab);
+        if (inA) hB = hL; else h = hL;
+    }
+    hA = (inA || inB) ? h : 0xFFu;
+}
+
 // The reference's arithmetic for ONE pixel (lane-private): window origin (prow, pcol) in the gradient tile.  Same
 // operations in the same order as hash_phase (column accumulators over the 11 patch rows, sumitup_ps_512 fold), then
 // the flavour logic of hash_phase's epilogue.
@@ -718,20 +750,49 @@ __device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& g
     }
     const f2 ad = (holdAD + curAD) + t1AD;
     const float bb = (holdB + curB) + t1B;
-    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
-    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
-    hA = 0xFFu; hB = 0xFFu;
-    unsigned h = 0xFFu;
-    if (inA) {
-        bool rare = false;
-        h = (unsigned)hash_px_impl<0>(ad.x, bb, ad.y, HQ, sTab, rare);
-        if (rare) h = (unsigned)hash_px_generic(ad.x, bb, ad.y, HQ, sTab);
+    flavour_hash(P, sTab, ad.x, bb, ad.y, c, hA, hB);
+}
+
+// Exact tensor of up to four worklist pixels per wave with 16 lanes per pixel: lane l < 11 of a group runs the
+// reference's chain of patch column l (the 11 patch rows in order, weights wl[i] = wT[l][i]); the 11 column sums are
+// folded in sumitup_ps_512's association with DPP row shifts (row_shl:n -- lane i reads lane i+n of its row of 16):
+//   u = S + shl8(S): lanes 0..2 = S0+S8, S1+S9, S2+S10;  v = u + shl4(S): Ga, Gb, Gd;  lane 3: S3 + S7 = Gc;
+//   r = z + shl2(z): lane 0 = Ga+Gd, lane 1 = Gb+Gc;  lane 0: (Ga+Gd) + (Gb+Gc)  [fp addition commutes bit for bit].
+// The latency of one round is ~11 rows instead of 121 taps: what matters when only a handful of pixels per tile need it.
+template <int CTRL>
+__device__ __forceinline__ float row_shl(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fold11(float S, bool lane3)
+{
+    const float u = S + row_shl<0x108>(S);
+    const float v = u + row_shl<0x104>(S);
+    const float wv = S + row_shl<0x104>(S);
+    const float z = lane3 ? wv : v;
+    const float r = z + row_shl<0x102>(z);
+    return r + row_shl<0x101>(r);
+}
+__device__ __forceinline__ void exact_tensor16(const f2* sG, const float (&wl)[11], int prow, int pcol, int l, float& a, float& b, float& d)
+{
+    constexpr int GW_ = 74;
+    const f2* base = sG + prow * GW_ + pcol + min(l, 10);
+    f2 AD = {0.f, 0.f};
+    float B = 0.f;
+    f2 gg[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) gg[i] = base[i * GW_];
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        const f2 w2 = {wl[i], wl[i]};
+        const f2 pq = gg[i] * w2;
+        AD = __builtin_elementwise_fma(pq, gg[i], AD);
+        B = __builtin_fmaf(pq.x, gg[i].y, B);
     }
-    if (inB) {
-        const unsigned hL = (unsigned)hash_px_legacy(ad.x, bb, ad.y, HQ, sTab);
-        if (inA) hB = hL; else h = hL;
-    }
-    hA = (inA || inB) ? h : 0xFFu;
+    const bool lane3 = l == 3;
+    a = fold11(AD.x, lane3);
+    b = fold11(B, lane3);
+    d = fold11(AD.y, lane3);
 }
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
@@ -739,7 +800,7 @@ __device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& g
 template <int LW>
 __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const f2* sG, float4* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
-                                              int c0, int r0)
+                                              int c0, int r0, unsigned long long& tstamp)
 {
     constexpr int GW_ = 74, TW = 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -768,6 +829,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
     if (threadIdx.x == 0) sCnt[0] = 0;
     __syncthreads();
+    RAISR_STAMP(P, 2, tstamp);
 
     // ---- H pass: lane = column, wave w = row group ----
     float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f}, td[4] = {0.f, 0.f, 0.f, 0.f};
@@ -782,6 +844,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         td[0] = __builtin_fmaf(uk, xd.x, td[0]); td[1] = __builtin_fmaf(uk, xd.y, td[1]); td[2] = __builtin_fmaf(uk, xd.z, td[2]); td[3] = __builtin_fmaf(uk, xd.w, td[3]);
     }
 
+    RAISR_STAMP(P, 3, tstamp);
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
@@ -801,8 +864,8 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         // first hash: AVX-512 flavour where the column has one, else the AVX2 flavour; second hash: AVX2 flavour of the
         // re-hashed columns.  A certified bucket holds for both flavours (fl selects the wider table error there); the
         // zero tensor's bucket is looked up per flavour (computed once per tile with the exact code).
-        const unsigned bA = zero ? sList[1024 + (inA ? 0 : 1)] : bucket;
-        const unsigned bB = zero ? sList[1025] : bucket;
+        const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
+        const unsigned bB = zero ? (unsigned)P.zero_bucket[1] : bucket;
         const bool unc = zone && (!cert || P.cert_check);
         sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
         sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
@@ -815,25 +878,54 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     if (P.cert_stats) {
         if (nUnc) atomicAdd(&sCnt[1], nUnc);
     }
+    RAISR_STAMP(P, 4, tstamp);
     __syncthreads();
+    RAISR_STAMP(P, 5, tstamp);
 
-    // ---- worklist: the exact path for what could not be certified; <= 64 entries per wave and round ----
+    // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
     unsigned bad = 0;
-    for (unsigned base = 64u * w; base < n; base += 256u) {
-        const unsigned e = base + lane;
-        if (e < n) {
-            const unsigned ent = sList[e];
-            const int prow = (ent >> 6) & 15, pcol = ent & 63;
-            unsigned hA, hB;
-            exact_pixel(P, gw, sG, sTab, prow, pcol, c0 + pcol, hA, hB);
-            if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
-            sH[prow * TW + pcol] = (uint8_t)hA;
-            sH2[prow * TW + pcol] = (uint8_t)hB;
+    if (n <= 48u) {
+        // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
+        if (n) {
+            const int g = lane >> 4, l = lane & 15;
+            float wl[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) wl[i] = P.gauss_dev[min(l, 10) * 12 + i];
+            for (unsigned rd = (unsigned)w; 4u * rd < n; rd += 4u) {
+                const unsigned e = 4u * rd + (unsigned)g;
+                const unsigned ent = sList[min(e, n - 1u)];
+                const int prow = (ent >> 6) & 15, pcol = ent & 63;
+                float a, b, d;
+                exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
+                if (l == 0 && e < n) {
+                    unsigned hA, hB;
+                    flavour_hash(P, sTab, a, b, d, c0 + pcol, hA, hB);
+                    if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
+                    sH[prow * TW + pcol] = (uint8_t)hA;
+                    sH2[prow * TW + pcol] = (uint8_t)hB;
+                }
+            }
+        }
+    } else {
+        // long list (synthetic content, self-check mode): one lane per pixel, 64 pixels per wave and round
+        for (unsigned base = 64u * w; base < n; base += 256u) {
+            const unsigned e = base + lane;
+            if (e < n) {
+                const unsigned ent = sList[e];
+                const int prow = (ent >> 6) & 15, pcol = ent & 63;
+                unsigned hA, hB;
+                exact_pixel(P, gw, sG, sTab, prow, pcol, c0 + pcol, hA, hB);
+                if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
+                sH[prow * TW + pcol] = (uint8_t)hA;
+                sH2[prow * TW + pcol] = (uint8_t)hB;
+            }
         }
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
+    RAISR_STAMP(P, 6, tstamp);
     if (n) __syncthreads();                                // (n is the same in every thread)
+    RAISR_STAMP(P, 7, tstamp);
 }
 
 #include "raisr_fp16_kernels.h"
@@ -1030,7 +1122,8 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // k_hashfilter_ac: k_hashfilter with the certified hash stage (hash_phase_ac) -- the production kernel of the fp32
 // numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
 // pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
-template <typename T>
+// PART (profiling aid, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only (bucket 0).
+template <typename T, int PART = 0>
 __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                           uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
@@ -1042,7 +1135,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     __shared__ uint2 sTab[128];
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];
-    __shared__ uint16_t sList[1024 + 2];      // worklist entries; [1024], [1025]: bucket of the zero tensor per flavour
+    __shared__ uint16_t sList[1024];          // worklist entries
     __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1050,10 +1143,12 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
+    unsigned long long tstamp = P.prof ? clock64() : 0ull;
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
     if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
+    RAISR_STAMP(P, 0, tstamp);
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
@@ -1072,14 +1167,14 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
             const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
             if (idx < NR) grad(ty, tx);
         }
-        if (threadIdx.x < 2) {                 // bucket of the all-zero tensor in both flavours (flat windows)
-            const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
-            sList[1024 + threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? hash_px_generic(0.f, 0.f, 0.f, HQ, sTab)
-                                                                    : hash_px_legacy(0.f, 0.f, 0.f, HQ, sTab));
-        }
     }
     __syncthreads();
-    hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0);
+    RAISR_STAMP(P, 1, tstamp);
+    if (PART != 2) hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
+    else {
+        for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)((i * 7) % 216); sH2[i] = 0xFFu; }
+        __syncthreads();
+    }
     if (P.write_hash) {
         const int c = c0 + lane;
 #pragma unroll
@@ -1094,7 +1189,80 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
-    filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
+    if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
+    else if (sH[threadIdx.x] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+    RAISR_STAMP(P, 8, tstamp);
+}
+
+
+// k_hash_ac: the certified hash stage as a kernel of its own (bucket plane in HBM, 1 B per pixel; the filter stage
+// runs as k_filter / k_filter_lds).  The LR window is dead once the gradient tile exists, so the bucket tile and the
+// worklist live in its LDS space: 39 KB per workgroup, 4 workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                    uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+{
+    constexpr int TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
+    __shared__ float sL[LH * LW];             // 8624 B; after the gradient stage: sH [1024] | sH2 [1024] | sList [1024 x u16]
+    __shared__ f2 sG[GH * GW_];
+    __shared__ float4 sV[3 * 4 * GW_];
+    __shared__ uint2 sTab[128];
+    __shared__ unsigned sCnt[3];
+    static_assert(sizeof(float) * LH * LW >= 2 * TH * TW + 2 * 1024, "bucket tile and worklist fit the LR window's space");
+    uint8_t* sH = reinterpret_cast<uint8_t*>(sL);
+    uint8_t* sH2 = sH + TH * TW;
+    uint16_t* sList = reinterpret_cast<uint16_t*>(sH2 + TH * TW);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    unsigned long long tstamp = P.prof ? clock64() : 0ull;
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    RAISR_STAMP(P, 0, tstamp);
+    {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
+            const unsigned idx = threadIdx.x + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
+    }
+    __syncthreads();
+    RAISR_STAMP(P, 1, tstamp);
+    hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = r0 + 4 * w + j;
+        if (r < P.H - kMargin && c < P.c_final) {
+            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
+            const unsigned hB = sH2[(4 * w + j) * TW + lane];
+            if (hB != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;
+        }
+    }
+    if (P.cert_stats && threadIdx.x == 0) {
+        const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
+        if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
+        if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
+        atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1280,6 +1448,7 @@ struct ModelDev {
     size_t bytes = 0;
     BlobHeader h{};
     bool valid = false;
+    int zero_bucket[2] = {0, 0};           // bucket of the all-zero tensor, AVX-512 / AVX2 flavour (from the device hash code)
 };
 
 struct KernelTimer {
@@ -1368,7 +1537,10 @@ struct raisr_hip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // chroma lane of raisr_hip_process_host (overlaps the Y path)
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
-    bool certify = true;                       // certified hash stage (k_hashfilter_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernel
+    bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
+    bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
+    float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
+    unsigned long long* d_prof = nullptr;      // RAISR_HIP_PHASES=1: per-phase shader-clock cycles of the certified hash stage
     int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
     unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
     SepW sep{};
@@ -1465,6 +1637,9 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
     P.tab14 = c->d_tab14;
     P.lut_legacy = c->d_lut;
+    P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
+    P.gauss_dev = c->d_gauss;
+    P.prof = c->d_prof;
     {   // b == 0 in the reference's hash (Raisr_AVX512.cpp:151-173,204-233): xx = 1, ay = |0| + 1e-10, same fp32 operations
         volatile float one = 1.0f, tiny = 1e-10f;
         const float x1 = one, ay = 0.0f + tiny;
@@ -1490,12 +1665,27 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
-        if (c->fused && c->certify) {
+        if (c->fused && c->certify && c->split) {
+            P.cert_stats = c->d_cert_stats;
+            P.cert_check = c->cert_check;
+            timer_begin(c, "k_hash_ac", s, slot);
+            hipLaunchKernelGGL((k_hash_ac<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_filter", s, slot);
+            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else if (c->fused && c->certify) {
             P.write_hash = c->keep_hash_plane;
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
             timer_begin(c, "k_hashfilter_ac", s, slot);
-            hipLaunchKernelGGL((k_hashfilter_ac<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
+            if (part == 1)
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            else if (part == 2)
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            else
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
@@ -1670,6 +1860,12 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
+    HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
+    if (const char* e = getenv("RAISR_HIP_PHASES")) if (atoi(e)) {
+        HIP_TRY(hipMalloc((void**)&c->d_prof, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+    }
     int rc = pool_get_stream(c->device, &c->stream);
     if (rc) return rc;
     rc = pool_get_stream(c->device, &c->stream2);
@@ -1727,6 +1923,15 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
     if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
+    if (c->d_gauss) (void)hipFree(c->d_gauss);
+    if (c->d_prof) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, c->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[0]) {
+            fprintf(stderr, "[raisr-hip phases] cycles of wave 0 per phase, summed over tiles: stage %llu grad %llu vpass %llu hpass %llu hash %llu barrier %llu fixup %llu barrier %llu filter %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        }
+        (void)hipFree(c->d_prof);
+    }
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
     pool_put_stream(c->device, c->stream);
     pool_put_stream(c->device, c->stream2);
@@ -1772,6 +1977,28 @@ int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, 
     return RAISR_HIP_OK;
 }
 
+// Bucket of the all-zero structure tensor (flat windows) in both hash flavours, from the device's exact hash code:
+// the certified hash stage looks it up instead of hashing (0, 0, 0) per pixel.
+static int compute_zero_buckets(raisr_hip_ctx* c, int pass_index)
+{
+    ModelDev& m = c->model[pass_index];
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, 2) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    uint8_t h[2] = {0, 0};
+    if (hipMemset(d_in, 0, 3 * sizeof(float)) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemset");
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    for (int legacy = 0; legacy < 2 && !rc; legacy++) {
+        hipLaunchKernelGGL(k_debug_hash, dim3(1), dim3(256), 0, c->stream, d_in, 1u, P, legacy, d_out + legacy);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_hash");
+    }
+    if (!rc && hipMemcpy(h, d_out, 2, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    m.zero_bucket[0] = h[0]; m.zero_bucket[1] = h[1];
+    return rc;
+}
+
 int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void* device_blob, size_t bytes, void* stream)
 {
     if (!c || !device_blob || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
@@ -1790,7 +2017,7 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     HIP_TRY(hipMemcpyAsync(m.blob, device_blob, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     m.bytes = bytes; m.h = h; m.valid = true;
-    return RAISR_HIP_OK;
+    return compute_zero_buckets(c, pass_index);
 }
 
 int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,
@@ -1808,7 +2035,7 @@ int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int
     if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
     HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
     m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true;
-    return RAISR_HIP_OK;
+    return compute_zero_buckets(c, pass_index);
 }
 
 int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
@@ -1839,6 +2066,7 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     c->cfg = *cfg;
     c->gauss = make_gauss(cfg->bits);
     c->sep = make_sep(c->gauss);
+    HIP_TRY(hipMemcpy(c->d_gauss, &c->gauss, sizeof(GaussW), hipMemcpyHostToDevice));
     const bool mode2 = cfg->passes == 2 && cfg->two_pass_mode == 2;
     c->passW[0] = mode2 ? cfg->in_width : cfg->out_width;
     c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
