@@ -221,44 +221,69 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
 // rolled form waited for each load in turn, i.e. ~9 dependent memory round trips at the head of every
 // workgroup.
 // ------------------------------------------------------------------------------------------------
-template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
-__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
+template <int LH, int LWLOAD, typename T>
+struct TileRegs {
+    static constexpr int REM = LWLOAD - 64;                    // halo columns right of the first 64
+    static constexpr int NM = (LH + 3) / 4;                    // rows per wave in the main part
+    static constexpr unsigned NR = LH * REM, NRL = (NR + 255u) / 256u;
+    T vm[NM];
+    T vr[NRL];
+};
+
+// global -> registers half of stage_tile (all loads in flight, nothing waits): lets a persistent workgroup fetch the
+// next tile while it computes the current one
+template <int LH, int LWLOAD, typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TileRegs<LH, LWLOAD, T>& R)
 {
     static_assert(LWLOAD > 64 && LWLOAD <= 128, "a tile row is one 64-lane sweep plus a remainder");
-    constexpr int REM = LWLOAD - 64;                    // halo columns right of the first 64
-    constexpr int NM = (LH + 3) / 4;                    // rows per wave in the main part
-    constexpr unsigned NR = LH * REM, NRL = (NR + 255u) / 256u;
+    using TR = TileRegs<LH, LWLOAD, T>;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the row arithmetic stays scalar
     __builtin_assume(w >= 0 && w < 4);
     // main part: wave w sweeps columns [0,64) of rows w, w+4, ...: one clamped column index per lane for all rows
     const int gxm = min(max(x0 + lane, 0), W - 1);
-    T vm[NM];
 #pragma unroll
-    for (int it = 0; it < NM; it++) {
+    for (int it = 0; it < TR::NM; it++) {
         const int gy = min(max(y0 + min(w + 4 * it, LH - 1), 0), H - 1);
-        vm[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gxm];          // planes are < 2^31 samples: 32-bit offsets
+        R.vm[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gxm];          // planes are < 2^31 samples: 32-bit offsets
     }
     // remainder: the REM right-hand columns of all rows, spread linearly over the block
-    T vr[NRL];
 #pragma unroll
-    for (unsigned it = 0; it < NRL; it++) {
-        const unsigned idx = min(threadIdx.x + 256u * it, NR - 1u);
-        const int ty = (int)(idx / REM), tx = 64 + (int)(idx - (unsigned)ty * REM);
+    for (unsigned it = 0; it < TR::NRL; it++) {
+        const unsigned idx = min(threadIdx.x + 256u * it, TR::NR - 1u);
+        const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
         const int gy = min(max(y0 + ty, 0), H - 1), gx = min(max(x0 + tx, 0), W - 1);
-        vr[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gx];
+        R.vr[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gx];
     }
+}
+
+// registers -> LDS half (converting each sample to TL)
+template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
+__device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL* sL)
+{
+    using TR = TileRegs<LH, LWLOAD, T>;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(w >= 0 && w < 4);
 #pragma unroll
-    for (int it = 0; it < NM; it++) {
+    for (int it = 0; it < TR::NM; it++) {
         const int ty = w + 4 * it;
-        if (ty < LH) sL[ty * LSTRIDE + lane] = (TL)(float)vm[it];
+        if (ty < LH) sL[ty * LSTRIDE + lane] = (TL)(float)R.vm[it];
     }
 #pragma unroll
-    for (unsigned it = 0; it < NRL; it++) {
+    for (unsigned it = 0; it < TR::NRL; it++) {
         const unsigned idx = threadIdx.x + 256u * it;
-        const int ty = (int)(idx / REM), tx = 64 + (int)(idx - (unsigned)ty * REM);
-        if (idx < NR) sL[ty * LSTRIDE + tx] = (TL)(float)vr[it];
+        const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
+        if (idx < TR::NR) sL[ty * LSTRIDE + tx] = (TL)(float)R.vr[it];
     }
+}
+
+template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
+{
+    TileRegs<LH, LWLOAD, T> R;
+    load_tile<LH, LWLOAD>(src, pitch, W, H, y0, x0, R);
+    store_tile<LH, LWLOAD, LSTRIDE>(R, sL);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,16 +820,13 @@ __device__ __forceinline__ void exact_tensor16(const f2* sG, const float (&wl)[1
     d = fold11(AD.y, lane3);
 }
 
-// hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
-// (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
-template <int LW>
-__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const f2* sG, float4* sV,
-                                              const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
-                                              int c0, int r0, unsigned long long& tstamp)
+// Approximate structure tensor of the lane's 4 pixels (rows [4w, 4w+4) of the tile, column = lane): separable 11 + 11 taps
+// on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4),
+// results as float4 per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
+__device__ __forceinline__ void tensor_ac(const SepW& S, const f2* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4])
 {
-    constexpr int GW_ = 74, TW = 64;
+    constexpr int GW_ = 74;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // ---- V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4) ----
     auto vpass = [&](int x, int rg) {
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -827,23 +849,44 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     };
     vpass(lane, w);
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
-    if (threadIdx.x == 0) sCnt[0] = 0;
     __syncthreads();
-    RAISR_STAMP(P, 2, tstamp);
-
-    // ---- H pass: lane = column, wave w = row group ----
-    float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f}, td[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
+    // software-pipelined by hand (next column's three float4 in flight during this column's 12 FMAs) and fenced per
+    // column: left alone, the scheduler issues all 33 loads first and sinks the FMAs into the hash code -- 132 live VGPRs
+    float4 xa = sV[(0 * 4 + w) * GW_ + lane], xb = sV[(1 * 4 + w) * GW_ + lane], xd = sV[(2 * 4 + w) * GW_ + lane];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
-        const float4 xa = sV[(0 * 4 + w) * GW_ + lane + k];
-        const float4 xb = sV[(1 * 4 + w) * GW_ + lane + k];
-        const float4 xd = sV[(2 * 4 + w) * GW_ + lane + k];
+        float4 na = xa, nb = xb, nd = xd;
+        if (k < 10) {
+            na = sV[(0 * 4 + w) * GW_ + lane + k + 1];
+            nb = sV[(1 * 4 + w) * GW_ + lane + k + 1];
+            nd = sV[(2 * 4 + w) * GW_ + lane + k + 1];
+        }
         const float uk = S.us[k];
         ta[0] = __builtin_fmaf(uk, xa.x, ta[0]); ta[1] = __builtin_fmaf(uk, xa.y, ta[1]); ta[2] = __builtin_fmaf(uk, xa.z, ta[2]); ta[3] = __builtin_fmaf(uk, xa.w, ta[3]);
         tb[0] = __builtin_fmaf(uk, xb.x, tb[0]); tb[1] = __builtin_fmaf(uk, xb.y, tb[1]); tb[2] = __builtin_fmaf(uk, xb.z, tb[2]); tb[3] = __builtin_fmaf(uk, xb.w, tb[3]);
         td[0] = __builtin_fmaf(uk, xd.x, td[0]); td[1] = __builtin_fmaf(uk, xd.y, td[1]); td[2] = __builtin_fmaf(uk, xd.z, td[2]); td[3] = __builtin_fmaf(uk, xd.w, td[3]);
+        xa = na; xb = nb; xd = nd;
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // pin the 12 sums here: otherwise LLVM sinks the FMAs of rows 1..3 into the per-pixel hash code and keeps (spills) the loaded columns
+#pragma unroll
+    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(ta[r]), "+v"(tb[r]), "+v"(td[r]));
+}
 
+// hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
+// (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
+template <int LW>
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const f2* sG, float4* sV,
+                                              const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
+                                              int c0, int r0, unsigned long long& tstamp)
+{
+    constexpr int GW_ = 74, TW = 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCnt[0] = 0;
+    float ta[4], tb[4], td[4];
+    tensor_ac(S, sG, sV, ta, tb, td);
     RAISR_STAMP(P, 3, tstamp);
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
@@ -1054,8 +1097,10 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
-                                                PassParams P, float* __restrict__ hr)
+                                                PassParams P, float* __restrict__ hr, unsigned* __restrict__ fix_counters = nullptr)
 {
+    // split pipeline: this launch follows the fix kernels in stream order, so their list counters can be cleared here
+    if (fix_counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fix_counters[0] = 0;
     constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
     __shared__ float sL[LH * LW];
     __shared__ uint8_t sH[TH * TW];         // first hash (0xFF = not filtered)
@@ -1195,74 +1240,241 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
 }
 
 
-// k_hash_ac: the certified hash stage as a kernel of its own (bucket plane in HBM, 1 B per pixel; the filter stage
-// runs as k_filter / k_filter_lds).  The LR window is dead once the gradient tile exists, so the bucket tile and the
-// worklist live in its LDS space: 39 KB per workgroup, 4 workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+// Split pipeline of the fp32 numerics:  k_hash_ac -> k_fix_sparse -> k_fix_dense -> filter kernel.
+// k_hash_ac computes the approximate tensor and the certified buckets of a 64 x 16 tile and writes one bucket per pixel
+// (HBM, 1 B/pixel).  Pixels it cannot certify do NOT stall the tile: a tile with few of them appends their coordinates
+// to a frame-level list (k_fix_sparse: exact tensor with 16 lanes per pixel, straight from the LR plane), a tile with
+// many appends itself to the tile list (k_fix_dense: the all-exact hash_phase on those tiles).  Both lists are usually
+// short or empty; the fix kernels are persistent grids that read the counts on the device.
+// ------------------------------------------------------------------------------------------------
+struct FixLists {
+    unsigned* counts;            // per tile: number of listed pixels (0 .. kSparseMax), or kDenseTile; written by k_hash_ac every frame
+    unsigned* sparse;            // [tile][kSparseMax]: (row << 16) | column
+    unsigned* dense;             // (tile row << 16) | tile column
+    unsigned* counters;          // [0] number of dense tiles; zeroed by the filter kernel that follows
+    uint8_t* cert_mask;          // self-check mode: 1 where the bucket in the plane was certified (else null)
+    int tiles_x, tiles_y;
+};
+constexpr unsigned kSparseMax = 96;          // a tile with more uncertain pixels than this is re-hashed as a whole
+constexpr unsigned kDenseTile = 0xFFFFFFFFu;
+
+// xcd_tile for a linear tile index t of a persistent grid whose size is a multiple of 8 (so t % 8 == blockIdx.x % 8)
+__device__ __forceinline__ void xcd_tile_of(unsigned t, unsigned gx, unsigned n, int& bx, int& by)
+{
+    const unsigned n8 = n & ~7u;
+    const unsigned u = t < n8 ? (t & 7u) * (n8 >> 3) + (t >> 3) : t;
+    by = (int)(u / gx);
+    bx = (int)(u - (unsigned)by * gx);
+}
+
+// Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the next tile's LR window
+// into registers while it computes the current one.
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+__global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, PassParams P, SepW S, FixLists F,
                                                     uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
 {
     constexpr int TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
-    __shared__ float sL[LH * LW];             // 8624 B; after the gradient stage: sH [1024] | sH2 [1024] | sList [1024 x u16]
+    __shared__ float sL[LH * LW];             // 8624 B; after the gradient stage: worklist [1024 x u16]
     __shared__ f2 sG[GH * GW_];
     __shared__ float4 sV[3 * 4 * GW_];
-    __shared__ uint2 sTab[128];
-    __shared__ unsigned sCnt[3];
-    static_assert(sizeof(float) * LH * LW >= 2 * TH * TW + 2 * 1024, "bucket tile and worklist fit the LR window's space");
-    uint8_t* sH = reinterpret_cast<uint8_t*>(sL);
-    uint8_t* sH2 = sH + TH * TW;
-    uint16_t* sList = reinterpret_cast<uint16_t*>(sH2 + TH * TW);
+    __shared__ unsigned sCnt[2];
+    uint16_t* sList = reinterpret_cast<uint16_t*>(sL);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int bx, by;
-    xcd_tile(bx, by);
-    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+    const unsigned ntiles = (unsigned)(F.tiles_x * F.tiles_y);
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    TileRegs<LH, 76, T> R;
+    unsigned t = blockIdx.x;
+    int bx = 0, by = 0;
+    if (t < ntiles) {
+        xcd_tile_of(t, (unsigned)F.tiles_x, ntiles, bx, by);
+        load_tile<LH, 76>(lr, P.lr_pitch, P.W, P.H, by * TH, bx * TW, R);      // window origin (r0 - 6, c0 - 6) = (by TH, bx TW)
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+        const unsigned tile_id = (unsigned)by * (unsigned)F.tiles_x + (unsigned)bx;
+        const unsigned tile_pos = ((unsigned)by << 16) | (unsigned)bx;
+        if (threadIdx.x < 2) sCnt[threadIdx.x] = 0;
+        store_tile<LH, 76, LW>(R, sL);
+        __syncthreads();
+        if (t + gridDim.x < ntiles) {                       // next tile's window: in flight during this tile's arithmetic
+            xcd_tile_of(t + gridDim.x, (unsigned)F.tiles_x, ntiles, bx, by);
+            load_tile<LH, 76>(lr, P.lr_pitch, P.W, P.H, by * TH, bx * TW, R);
+        }
+        {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+            auto grad = [&](int ty, int tx) {
+                const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+                const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+                sG[ty * GW_ + tx] = (f2){gxv, gyv};
+            };
+            const int wu = __builtin_amdgcn_readfirstlane(w);
+            __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+            for (int it = 0; it < (GH + 3) / 4; it++)
+                if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+            constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+            for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
+                const unsigned idx = threadIdx.x + 256u * it;
+                const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+                if (idx < NR) grad(ty, tx);
+            }
+        }
+        __syncthreads();
+        float ta[4], tb[4], td[4];
+        tensor_ac(S, sG, sV, ta, tb, td);
 
-    unsigned long long tstamp = P.prof ? clock64() : 0ull;
+        const int c = c0 + lane;
+        const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+        const int fl = inB ? 1 : 0;
+        unsigned nUnc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int prow = 4 * w + j;
+            const int r = r0 + prow;
+            const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
+            unsigned bucket;
+            bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, P.ai_bzero, bucket);
+            const bool zero = (ta[j] + td[j]) == 0.0f;
+            cert |= zero;
+            const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
+            const unsigned bB = zero ? (unsigned)P.zero_bucket[1] : bucket;
+            if (r < P.H - kMargin && c < P.c_final) {
+                hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
+                if (inA && inB) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)bB;
+                if (F.cert_mask) F.cert_mask[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)(cert ? 1 : 0);
+            }
+            if (zone && (!cert || P.cert_check)) {
+                const unsigned slot = atomicAdd(&sCnt[0], 1u);
+                sList[slot] = (uint16_t)((prow << 6) | lane);
+            }
+            nUnc += (zone && !cert) ? 1u : 0u;
+        }
+        if (P.cert_stats && nUnc) atomicAdd(&sCnt[1], nUnc);
+        __syncthreads();
+        const unsigned n = sCnt[0];
+        if (n <= kSparseMax) {
+            if (threadIdx.x < n) {
+                const unsigned ent = sList[threadIdx.x];
+                F.sparse[tile_id * kSparseMax + threadIdx.x] = ((unsigned)(r0 + (int)((ent >> 6) & 15)) << 16) | (unsigned)(c0 + (int)(ent & 63));
+            }
+            if (threadIdx.x == 0) F.counts[tile_id] = n;
+        } else if (threadIdx.x == 0) {
+            F.counts[tile_id] = kDenseTile;
+            F.dense[atomicAdd(&F.counters[0], 1u)] = tile_pos;
+        }
+        if (P.cert_stats && threadIdx.x == 0) {
+            const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
+            if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
+            atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
+        }
+        __syncthreads();                                     // worklist (in the LR window's space) and counters are free again
+    }
+}
+
+// k_fix_sparse: the reference's exact tensor + hash for the listed pixels of one tile per wave: tensors with 16 lanes per
+// pixel (exact_tensor16's scheme, the 13 x 13 LR window read straight from the L2-resident plane), parked in LDS, then
+// one hash pass with a lane per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_fix_sparse(const T* __restrict__ lr, PassParams P, FixLists F,
+                                                    uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+{
+    __shared__ uint2 sTab[128];
+    __shared__ float sABD[4][kSparseMax][3];
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
-    if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
-    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
-    RAISR_STAMP(P, 0, tstamp);
-    {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
-        auto grad = [&](int ty, int tx) {
-            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
-            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
-            sG[ty * GW_ + tx] = (f2){gxv, gyv};
-        };
-        const int wu = __builtin_amdgcn_readfirstlane(w);
-        __builtin_assume(wu >= 0 && wu < 4);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, l = lane & 15, lc = min(l, 10);
+    const unsigned tile = blockIdx.x * 4u + (unsigned)wv;
+    if (tile >= (unsigned)(F.tiles_x * F.tiles_y)) return;
+    const unsigned n = F.counts[tile];
+    if (n == 0 || n == kDenseTile) return;
+    const unsigned* list = F.sparse + (size_t)tile * kSparseMax;
+    float wl[11];
 #pragma unroll
-        for (int it = 0; it < (GH + 3) / 4; it++)
-            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
-        constexpr unsigned NR = GH * (GW_ - 64);
+    for (int i = 0; i < 11; i++) wl[i] = P.gauss_dev[lc * 12 + i];
+    for (unsigned rd = 0; 4u * rd < n; rd++) {
+        const unsigned e = 4u * rd + (unsigned)g;
+        const unsigned ent = list[min(e, n - 1u)];
+        const int r = (int)(ent >> 16), c = (int)(ent & 0xFFFFu);
+        // column x = c - 5 + l of the window: rows r-6 .. r+6 of it, rows r-5 .. r+5 of its two neighbours
+        const T* col = lr + (unsigned)(r - 6) * (unsigned)P.lr_pitch + (unsigned)(c - 5 + lc);
+        float Lc[13], Ll[11], Lr[11];
 #pragma unroll
-        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
-            const unsigned idx = threadIdx.x + 256u * it;
-            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
-            if (idx < NR) grad(ty, tx);
+        for (int j = 0; j < 13; j++) Lc[j] = (float)col[(unsigned)j * (unsigned)P.lr_pitch];
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            Ll[i] = (float)col[(unsigned)(i + 1) * (unsigned)P.lr_pitch - 1];
+            Lr[i] = (float)col[(unsigned)(i + 1) * (unsigned)P.lr_pitch + 1];
+        }
+        f2 AD = {0.f, 0.f};
+        float B = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const f2 gg = {Lc[i + 2] - Lc[i], Lr[i] - Ll[i]};          // GetGx: row below - row above; GetGy: right - left
+            const f2 w2 = {wl[i], wl[i]};
+            const f2 pq = gg * w2;
+            AD = __builtin_elementwise_fma(pq, gg, AD);
+            B = __builtin_fmaf(pq.x, gg.y, B);
+        }
+        const bool lane3 = l == 3;
+        const float a = fold11(AD.x, lane3), b = fold11(B, lane3), d = fold11(AD.y, lane3);
+        if (l == 0 && e < n) { sABD[wv][e][0] = a; sABD[wv][e][1] = b; sABD[wv][e][2] = d; }
+    }
+    __builtin_amdgcn_wave_barrier();                          // LDS is in order within a wave
+    unsigned bad = 0;
+    for (unsigned e = (unsigned)lane; e < n; e += 64u) {
+        const unsigned ent = list[e];
+        const int r = (int)(ent >> 16), c = (int)(ent & 0xFFFFu);
+        unsigned hA, hB;
+        flavour_hash(P, sTab, sABD[wv][e][0], sABD[wv][e][1], sABD[wv][e][2], c, hA, hB);
+        const unsigned idx = (unsigned)r * (unsigned)P.hash_pitch + (unsigned)c;
+        if (F.cert_mask && F.cert_mask[idx] && (hash_out[idx] != (uint8_t)hA || (hB != 0xFFu && hash2_out[(size_t)r * 16 + (c - P.ov_begin)] != (uint8_t)hB))) bad++;
+        hash_out[idx] = (uint8_t)hA;
+        if (hB != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;
+    }
+    if (P.cert_stats && bad) atomicAdd(&P.cert_stats[1], bad);
+}
+
+// k_fix_dense: the all-exact hash stage (hash_phase) for the listed tiles.  Persistent grid.
+template <typename T, bool AVX2ALL>
+__global__ __launch_bounds__(256, 4) void k_fix_dense(const T* __restrict__ lr, PassParams P, GaussW gw, FixLists F,
+                                                      uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+{
+    constexpr int R = 4, TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[(TH + 10) * 74];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
+    const unsigned n = F.counters[0];
+    if (blockIdx.x >= n) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    stage_hash_tables<AVX2ALL>(P, sTab, sLut);
+    unsigned bad = 0;
+    for (unsigned t = blockIdx.x; t < n; t += gridDim.x) {
+        const unsigned tile = F.dense[t];
+        const int c0 = kMargin + (int)(tile & 0xFFFFu) * 64, r0 = kMargin + (int)(tile >> 16) * TH;
+        __syncthreads();                                    // the previous tile's LDS reads are done
+        stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+        __syncthreads();
+        unsigned hA[R], hB[R];
+        hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
+        const int c = c0 + lane;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int r = r0 + w * R + j;
+            if (r < P.H - kMargin && c < P.c_final) {
+                const unsigned idx = (unsigned)r * (unsigned)P.hash_pitch + (unsigned)c;
+                if (F.cert_mask && F.cert_mask[idx] && hA[j] != 0xFFu &&
+                    (hash_out[idx] != (uint8_t)hA[j] || (hB[j] != 0xFFu && hash2_out[(size_t)r * 16 + (c - P.ov_begin)] != (uint8_t)hB[j]))) bad++;
+                hash_out[idx] = (uint8_t)hA[j];
+                if (hB[j] != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB[j];
+            }
         }
     }
-    __syncthreads();
-    RAISR_STAMP(P, 1, tstamp);
-    hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
-    const int c = c0 + lane;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int r = r0 + 4 * w + j;
-        if (r < P.H - kMargin && c < P.c_final) {
-            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
-            const unsigned hB = sH2[(4 * w + j) * TW + lane];
-            if (hB != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB;
-        }
-    }
-    if (P.cert_stats && threadIdx.x == 0) {
-        const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
-        if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
-        if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
-        atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
-    }
+    if (P.cert_stats && bad) atomicAdd(&P.cert_stats[1], bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1540,6 +1752,8 @@ struct raisr_hip_ctx {
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
+    FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
+    size_t fix_tiles = 0;
     unsigned long long* d_prof = nullptr;      // RAISR_HIP_PHASES=1: per-phase shader-clock cycles of the certified hash stage
     int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
     unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
@@ -1668,11 +1882,27 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         if (c->fused && c->certify && c->split) {
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
+            FixLists F = c->fix;
+            if (c->cert_check) {                     // self-check: remember which buckets were certified
+                if (!c->fix.cert_mask && hipMalloc((void**)&c->fix.cert_mask, (size_t)c->cfg.out_width * c->cfg.out_height) != hipSuccess) c->fix.cert_mask = nullptr;
+                F.cert_mask = c->fix.cert_mask;
+            } else F.cert_mask = nullptr;
+            F.tiles_x = (int)gf.x; F.tiles_y = (int)gf.y;
+            const unsigned ntiles = gf.x * gf.y;
+            const unsigned npers = ntiles < 1024u ? ntiles : 1024u;          // 4 workgroups per CU resident (LDS), each walks ~ntiles/1024 tiles
             timer_begin(c, "k_hash_ac", s, slot);
-            hipLaunchKernelGGL((k_hash_ac<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hash2[pass]);
+            hipLaunchKernelGGL((k_hash_ac<TOut>), dim3(npers), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->sep, F, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_fix", s, slot);
+            hipLaunchKernelGGL((k_fix_sparse<TOut>), dim3((ntiles + 3u) / 4u), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, F, c->d_hash[pass], c->d_hash2[pass]);
+            const unsigned nd = (unsigned)(gf.x * gf.y < 2048u ? gf.x * gf.y : 2048u);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_fix_dense<TOut, false>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
+            else
+                hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             timer_begin(c, "k_filter", s, slot);
-            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
+            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
             timer_end(c, s, slot);
         } else if (c->fused && c->certify) {
             P.write_hash = c->keep_hash_plane;
@@ -1776,6 +2006,13 @@ void free_scratch(raisr_hip_ctx* c)
     }
     if (c->d_mid) (void)hipFree(c->d_mid);
     c->d_mid = nullptr;
+    if (c->fix.counters) (void)hipFree(c->fix.counters);
+    if (c->fix.counts) (void)hipFree(c->fix.counts);
+    if (c->fix.sparse) (void)hipFree(c->fix.sparse);
+    if (c->fix.dense) (void)hipFree(c->fix.dense);
+    if (c->fix.cert_mask) (void)hipFree(c->fix.cert_mask);
+    c->fix = FixLists{};
+    c->fix_tiles = 0;
 }
 
 }  // namespace
@@ -2081,6 +2318,22 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
             free_scratch(c);
             return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
         }
+    }
+    if (cfg->hash_variant != RAISR_HIP_HASH_FP16) {   // worklists of the split pipeline (largest pass geometry)
+        size_t tiles = 0;
+        for (int p = 0; p < cfg->passes; p++) {
+            const size_t t = (size_t)((c->passW[p] + 63) / 64) * (size_t)((c->passH[p] + 15) / 16);
+            if (t > tiles) tiles = t;
+        }
+        c->fix_tiles = tiles;
+        if (hipMalloc((void**)&c->fix.counters, 2 * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.counts, tiles * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.sparse, tiles * kSparseMax * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.dense, tiles * sizeof(unsigned)) != hipSuccess) {
+            free_scratch(c);
+            return fail(RAISR_HIP_ENOMEM, "worklist alloc");
+        }
+        HIP_TRY(hipMemset(c->fix.counters, 0, 2 * sizeof(unsigned)));
     }
     if (cfg->passes == 2) {
         // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
