@@ -1477,6 +1477,173 @@ __global__ __launch_bounds__(256, 4) void k_fix_dense(const T* __restrict__ lr, 
     if (P.cert_stats && bad) atomicAdd(&P.cert_stats[1], bad);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_filter_lds: the filter stage with the filter bank in LDS (north_star: "per-CU LDS cache").
+// The stand-alone k_filter is bound by the vector L1: 512 B of coefficients per pixel at 64 B/clk/CU.  One pixel
+// type's bank is 216 x 128 floats = 108 KB and fits the 160 KB LDS, where a lane fetches its 8 coefficients with two
+// ds_read_b128 (256 B/clk/CU).  So: persistent workgroups of 16 waves, one per CU, each owning ONE pixel type
+// (blockIdx & 3): it loads that type's bank once per launch and walks the tiles of its type -- 64 x 16 pixels of the
+// type = a 128 x 32 pixel region of the plane (SP = 2; ratio 1.5 has a single type and SP = 1) -- with the LR window of
+// the next tile (and its buckets) prefetched into registers while the current one is filtered.  Wave q of the workgroup
+// filters row q of the tile with the arithmetic of filter_phase (16 lanes per pixel, DPP tree, accept test).
+// LDS: bank 217 rows (row 216 = zeros: "not filtered") 111 104 B + 2 x LR window + 2 x bucket tiles.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int SP>
+__global__ __launch_bounds__(1024) void k_filter_lds(const T* __restrict__ lr, const uint8_t* __restrict__ hash, PassParams P,
+                                                     float* __restrict__ hr, unsigned* __restrict__ fix_counters)
+{
+    constexpr int TW = 64, TH = 16;                                  // pixels of the type per tile
+    constexpr int WW = SP * (TW - 1) + 11, WH = SP * (TH - 1) + 11;  // LR window of a tile: 137 x 41 (SP = 2), 74 x 26 (SP = 1)
+    constexpr int LW = SP == 2 ? 141 : 77;                           // row stride = 13 mod 32: a lane group's taps of two patch rows hit different banks
+    constexpr int NLOAD = (WW * WH + 1023) / 1024;
+    extern __shared__ float smem[];
+    float* sBank = smem;                                             // [217][2][16][4]
+    float* sT0 = sBank + 217 * 128;
+    float* sT1 = sT0 + WH * LW;
+    uint8_t* sHb = reinterpret_cast<uint8_t*>(sT1 + WH * LW);        // [2][2][TH * TW]: buffer, {first, second hash}
+
+    if (fix_counters && blockIdx.x == 0 && threadIdx.x == 0) fix_counters[0] = 0;   // follows the fix kernels in stream order
+    const int ntypes = SP * SP;
+    const int type = (int)(blockIdx.x % (unsigned)ntypes);
+    const int tr = type >> 1, tc = type & 1;
+    // first row / column of the filtered zone with this parity: t = ((r-5)&1)*2 + ((c-5)&1) (Raisr.cpp:1093)
+    const int rbase = SP == 2 ? kMargin + (tr ^ 1) : kMargin;
+    const int cbase = SP == 2 ? kMargin + (tc ^ 1) : kMargin;
+    const int ncols = (P.c_final - cbase + SP - 1) / SP, nrows = (P.H - kMargin - rbase + SP - 1) / SP;   // pixels of the type
+    const int tiles_x = (ncols + TW - 1) / TW, tiles_y = (nrows + TH - 1) / TH;
+    const int ntiles = (ncols > 0 && nrows > 0) ? tiles_x * tiles_y : 0;
+    const int wg = (int)(blockIdx.x / (unsigned)ntypes), nwg = (int)(gridDim.x / (unsigned)ntypes);
+
+    // ---- the type's bank: HBM [hash][type][128] -> LDS [hash][half][lane][4] (lane l's chunks 4 half .. 4 half + 3) ----
+    for (int e = (int)threadIdx.x; e < 217 * 128; e += 1024) {
+        const int h = e >> 7, k = e & 127, ch = k >> 4, l = k & 15;
+        const float v = h < 216 ? P.bank[((size_t)h * ntypes + type) * kTapsPad + k] : 0.0f;
+        sBank[h * 128 + (ch >> 2) * 64 + l * 4 + (ch & 3)] = v;
+    }
+
+    const int lane = threadIdx.x & 63, q = (int)(threadIdx.x >> 6);  // wave q <-> tile row q
+    const int g = lane >> 4, l = lane & 15;
+    int off[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) {
+        const int k = 16 * ch + l;
+        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;        // padding taps: coefficient is +0, any finite pixel will do
+    }
+
+    T regs[NLOAD];
+    unsigned rh = 0xFFu, rh2 = 0xFFu;
+    auto fetch = [&](int tile) {                                      // global -> registers: LR window and buckets of a tile
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int X0 = cbase + SP * TW * tx - 5, Y0 = rbase + SP * TH * ty - 5;
+#pragma unroll
+        for (int it = 0; it < NLOAD; it++) {
+            const int e = min((int)threadIdx.x + 1024 * it, WW * WH - 1);
+            const int wy = e / WW, wx = e - wy * WW;
+            const int gy = min(max(Y0 + wy, 0), P.H - 1), gx = min(max(X0 + wx, 0), P.W - 1);
+            regs[it] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gx];
+        }
+        const int r = rbase + SP * (TH * ty + q), c = cbase + SP * (TW * tx + lane);
+        const bool in = r < P.H - kMargin && c < P.c_final;
+        rh = in ? hash[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] : 0xFFu;
+        rh2 = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : 0xFFu;
+    };
+    auto stash = [&](int buf) {                                       // registers -> LDS buffer `buf`
+        float* sT = buf ? sT1 : sT0;
+#pragma unroll
+        for (int it = 0; it < NLOAD; it++) {
+            const int e = (int)threadIdx.x + 1024 * it;
+            const int wy = e / WW, wx = e - wy * WW;
+            if (e < WW * WH) sT[wy * LW + wx] = (float)regs[it];
+        }
+        sHb[(buf * 2 + 0) * TH * TW + q * TW + lane] = (uint8_t)rh;
+        sHb[(buf * 2 + 1) * TH * TW + q * TW + lane] = (uint8_t)rh2;
+    };
+
+    int tile = wg;
+    if (tile < ntiles) { fetch(tile); stash(0); }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < ntiles; tile += nwg, cur ^= 1) {
+        const int nxt = tile + nwg;
+        if (nxt < ntiles) fetch(nxt);                                 // in flight during this tile's arithmetic
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const float* sT = cur ? sT1 : sT0;
+        const uint8_t* sH = sHb + (cur * 2 + 0) * TH * TW + q * TW;
+        const uint8_t* sH2 = sHb + (cur * 2 + 1) * TH * TW + q * TW;
+        const int r = rbase + SP * (TH * ty + q);
+        {
+            // window row of image row r - 5 is SP q; pixel m of the row sits at window column SP m + 5
+            const float* rowbase = sT + (SP * q) * LW + SP * g;
+            const char* tap[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(rowbase + off[ch]);
+            const char* ctr = reinterpret_cast<const char*>(rowbase + 5 * LW + 5);
+#define RAISR_T_F(p, s) (*reinterpret_cast<const float*>((p) + (16 * SP) * (s)))
+            float keep = 0.0f;
+            const bool anyB = sH2[lane] != 0xFFu;
+            const char* ctrq = ctr + (64 * SP) * (l >> 2);           // centre pixel of the step this lane's quad ends up with
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float part[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    const int st = j + 4 * mm;
+                    const unsigned hA = min((unsigned)sH[4 * st + g], 216u);      // 0xFF (not filtered) -> the zero row
+                    const float4 fa = *reinterpret_cast<const float4*>(sBank + hA * 128u + (unsigned)l * 4u);
+                    const float4 fb = *reinterpret_cast<const float4*>(sBank + hA * 128u + 64u + (unsigned)l * 4u);
+                    float acc = RAISR_T_F(tap[0], st) * fa.x;
+                    acc = __builtin_fmaf(RAISR_T_F(tap[1], st), fa.y, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[2], st), fa.z, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[3], st), fa.w, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[4], st), fb.x, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[5], st), fb.y, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[6], st), fb.z, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[7], st), fb.w, acc);
+                    acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
+                    part[mm] = acc + row_ror<0x124>(acc);          // r4[i] = r8[i] + r8[i+4]
+                }
+                float v = part[0];
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[3]), "s"(0xf000f000f000f000ull));
+                v = v + quad_perm<0x4e>(v);
+                v = v + quad_perm<0xb1>(v);
+                float res = RAISR_T_F(ctrq, j);
+                if (v > P.lo && v < P.hi) res = v;
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
+            }
+            if (__any(anyB)) {                                       // tail columns: AVX2 re-hash (keep-first-if-rejected)
+#pragma unroll 1
+                for (int st = 0; st < 16; st++) {
+                    const unsigned hB = sH2[4 * st + g];
+                    if (hB == 0xFFu) continue;
+                    const float4 fa = *reinterpret_cast<const float4*>(sBank + hB * 128u + (unsigned)l * 4u);
+                    const float4 fb = *reinterpret_cast<const float4*>(sBank + hB * 128u + 64u + (unsigned)l * 4u);
+                    float acc = RAISR_T_F(tap[0], st) * fa.x;
+                    acc = __builtin_fmaf(RAISR_T_F(tap[1], st), fa.y, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[2], st), fa.z, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[3], st), fa.w, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[4], st), fb.x, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[5], st), fb.y, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[6], st), fb.z, acc);
+                    acc = __builtin_fmaf(RAISR_T_F(tap[7], st), fb.w, acc);
+                    const float v = tree16(acc);
+                    if (st == l) {
+                        if (v > P.lo && v < P.hi) keep = v;
+                        else if (P.randomness) keep = RAISR_T_F(ctr, st);
+                    }
+                }
+            }
+#undef RAISR_T_F
+            const int c = cbase + SP * (TW * tx + 4 * l + g);
+            if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
+        }
+        if (nxt < ntiles) stash(cur ^ 1);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_blend (CountOfBitsChanged): CTCountOfBitsChangedSegment_AVX256_32f, Raisr_AVX256.cpp:68-166,
 // plus the border policy of processSegment (Raisr.cpp:999-1028,1252-1265): row 0, row H-1, col 0,
@@ -1751,6 +1918,8 @@ struct raisr_hip_ctx {
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
+    bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
+    int n_cus = 256;                           // persistent k_filter_lds grid: one workgroup per CU (multiple of 4)
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
     FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
     size_t fix_tiles = 0;
@@ -1901,9 +2070,19 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             else
                 hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
-            timer_begin(c, "k_filter", s, slot);
-            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
-            timer_end(c, s, slot);
+            if (c->lds_filter) {
+                const bool sp2 = P.pixel_types == 4;
+                const int wh = sp2 ? 41 : 26, lw = sp2 ? 141 : 77;
+                const size_t shmem = (size_t)217 * 128 * 4 + 2 * (size_t)wh * lw * 4 + 4 * 1024;
+                timer_begin(c, "k_filter_lds", s, slot);
+                if (sp2) hipLaunchKernelGGL((k_filter_lds<TOut, 2>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                else hipLaunchKernelGGL((k_filter_lds<TOut, 1>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                timer_end(c, s, slot);
+            } else {
+                timer_begin(c, "k_filter", s, slot);
+                hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                timer_end(c, s, slot);
+            }
         } else if (c->fused && c->certify) {
             P.write_hash = c->keep_hash_plane;
             P.cert_stats = c->d_cert_stats;
@@ -2098,6 +2277,16 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
+    if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 4) c->n_cus = prop.multiProcessorCount & ~3;
+        // k_filter_lds declares ~160 KB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    }
     HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
     if (const char* e = getenv("RAISR_HIP_PHASES")) if (atoi(e)) {
         HIP_TRY(hipMalloc((void**)&c->d_prof, 16 * sizeof(unsigned long long)));
