@@ -1644,6 +1644,241 @@ __global__ __launch_bounds__(1024) void k_filter_lds(const T* __restrict__ lr, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_filter_lds16: k_filter_lds with the LR window held as binary16 and TWO pixels per lane and step.
+// 8- and 10-bit samples are exact in binary16, and v_fma_mix_f32 multiplies a binary16 operand (either half of a
+// VGPR) into an fp32 FMA -- bit for bit the fp32 FMA of the converted value.  The window is stored de-interleaved by
+// column parity (pixels of one type are SP columns apart, so the two pixels a lane works on are neighbours in their
+// parity plane), each plane twice: as is, and shifted by one sample, so that every (even-aligned) 4-byte read returns
+// the pair a lane needs.  Per 8 pixels: 8 ds_read_b32 (patch pairs) + 4 ds_read_b128 (coefficients) = 32 LDS cycles
+// instead of 48.  Pixel m = 8 ds + 2 g + e (ds = step 0..7, g = lane group, e = half); lane (g, l) keeps m with l = 2 ds + e.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_mix_lo(unsigned pair, float f, float acc)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(f), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned pair, float f, float acc)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(f), "v"(acc));
+    return d;
+}
+
+template <typename T, int SP>
+__global__ __launch_bounds__(1024) void k_filter_lds16(const T* __restrict__ lr, const uint8_t* __restrict__ hash, PassParams P,
+                                                       float* __restrict__ hr, unsigned* __restrict__ fix_counters)
+{
+    constexpr int TW = 64, TH = 16;                                  // pixels of the type per tile
+    constexpr int WW = SP * (TW - 1) + 11, WH = SP * (TH - 1) + 11;  // LR window of a tile: 137 x 41 (SP = 2), 74 x 26 (SP = 1)
+    // Row layout in binary16 samples: one region per (plane, copy), 70 (SP = 2) / 74 (SP = 1) samples each, placed so that the 32
+    // dwords a half-wave's ds_read_b32 touches (16 taps x 2 lane groups) fall into 32 different banks for every chunk
+    // (exhaustive search over region orders, gaps and row strides; SQ_LDS_BANK_CONFLICT 33 % -> ~0 of the LDS cycles)
+    constexpr int RS = SP == 2 ? 286 : 154;
+    constexpr int REG0 = SP == 2 ? 142 : 0, REG1 = SP == 2 ? 214 : 78, REG2 = 0, REG3 = 72;    // region of (plane * 2 + copy)
+    constexpr int NLOAD = (WW * WH + 1023) / 1024;
+    extern __shared__ float smem[];
+    float* sBank = smem;                                             // [217][2][16][4]
+    uint16_t* sT0 = reinterpret_cast<uint16_t*>(sBank + 217 * 128);
+    uint16_t* sT1 = sT0 + WH * RS;
+    uint8_t* sHb = reinterpret_cast<uint8_t*>(sT1 + WH * RS);        // [2][2][TH * TW]: buffer, {first, second hash}
+
+    if (fix_counters && blockIdx.x == 0 && threadIdx.x == 0) fix_counters[0] = 0;   // follows the fix kernels in stream order
+    const int ntypes = SP * SP;
+    const int type = (int)(blockIdx.x % (unsigned)ntypes);
+    const int tr = type >> 1, tc = type & 1;
+    const int rbase = SP == 2 ? kMargin + (tr ^ 1) : kMargin;
+    const int cbase = SP == 2 ? kMargin + (tc ^ 1) : kMargin;
+    const int ncols = (P.c_final - cbase + SP - 1) / SP, nrows = (P.H - kMargin - rbase + SP - 1) / SP;
+    const int tiles_x = (ncols + TW - 1) / TW, tiles_y = (nrows + TH - 1) / TH;
+    const int ntiles = (ncols > 0 && nrows > 0) ? tiles_x * tiles_y : 0;
+    const int wg = (int)(blockIdx.x / (unsigned)ntypes), nwg = (int)(gridDim.x / (unsigned)ntypes);
+
+    {   // the type's bank: 27 elements per thread, nine loads in flight at a time (a load -> store loop pays the memory latency 27 times)
+        constexpr int NB = 217 * 128;
+#pragma unroll 1
+        for (int e0 = (int)threadIdx.x; e0 < NB; e0 += 9 * 1024) {
+            float v[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++) {
+                const int e = e0 + 1024 * u, h = e >> 7, k = e & 127;
+                v[u] = (e < NB && h < 216) ? P.bank[((size_t)h * ntypes + type) * kTapsPad + k] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 9; u++) {
+                const int e = e0 + 1024 * u, h = e >> 7, k = e & 127, ch = k >> 4, l = k & 15;
+                if (e < NB) sBank[h * 128 + (ch >> 2) * 64 + l * 4 + (ch & 3)] = v[u];
+            }
+        }
+    }
+
+    const int lane = threadIdx.x & 63, q = (int)(threadIdx.x >> 6);  // wave q <-> tile row q
+    const int g = lane >> 4, l = lane & 15;
+    // sample offset of tap k = 16 ch + l for the lane's pixel pair of step 0 (m0 = 2 g): window column SP m + tj lives in plane
+    // tj % SP at index m + tj / SP; an odd index is read from the shifted copy at index - 1
+    int off[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) {
+        const int k = 16 * ch + l;
+        const int ti = k < kTaps ? k / 11 : 0, tj = k < kTaps ? k % 11 : 0;
+        const int pl = tj % SP, idx = tj / SP, cp = idx & 1;
+        const int reg = pl * 2 + cp;
+        off[ch] = ti * RS + (reg == 0 ? REG0 : reg == 1 ? REG1 : reg == 2 ? REG2 : REG3) + (idx - cp) + 2 * g;
+    }
+
+    T regs[NLOAD];
+    unsigned rh = 0xFFu, rh2 = 0xFFu;
+    auto fetch = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int X0 = cbase + SP * TW * tx - 5, Y0 = rbase + SP * TH * ty - 5;
+#pragma unroll
+        for (int it = 0; it < NLOAD; it++) {
+            const int e = min((int)threadIdx.x + 1024 * it, WW * WH - 1);
+            const int wy = e / WW, wx = e - wy * WW;
+            const int gy = min(max(Y0 + wy, 0), P.H - 1), gx = min(max(X0 + wx, 0), P.W - 1);
+            regs[it] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gx];
+        }
+        const int r = rbase + SP * (TH * ty + q), c = cbase + SP * (TW * tx + lane);
+        const bool in = r < P.H - kMargin && c < P.c_final;
+        rh = in ? hash[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] : 0xFFu;
+        rh2 = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : 0xFFu;
+    };
+    auto stash = [&](int buf) {
+        uint16_t* sT = buf ? sT1 : sT0;
+#pragma unroll
+        for (int it = 0; it < NLOAD; it++) {
+            const int e = (int)threadIdx.x + 1024 * it;
+            const int wy = e / WW, wx = e - wy * WW;
+            if (e < WW * WH) {
+                const uint16_t hv = __builtin_bit_cast(uint16_t, (_Float16)(float)regs[it]);     // exact: samples <= 1023
+                const int pl = wx % SP, idx = wx / SP;
+                uint16_t* row = sT + wy * RS;
+                row[(pl ? REG2 : REG0) + idx] = hv;                   // copy 0
+                if (idx > 0) row[(pl ? REG3 : REG1) + idx - 1] = hv;  // copy 1: shifted by one sample
+            }
+        }
+        sHb[(buf * 2 + 0) * TH * TW + q * TW + lane] = (uint8_t)rh;
+        sHb[(buf * 2 + 1) * TH * TW + q * TW + lane] = (uint8_t)rh2;
+    };
+
+    int tile = wg;
+    if (tile < ntiles) { fetch(tile); stash(0); }
+    __syncthreads();
+    int cur = 0;
+    const float negzero = -0.0f;
+    for (; tile < ntiles; tile += nwg, cur ^= 1) {
+        const int nxt = tile + nwg;
+        if (nxt < ntiles) fetch(nxt);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const uint16_t* sT = cur ? sT1 : sT0;
+        const uint8_t* sH = sHb + (cur * 2 + 0) * TH * TW + q * TW;
+        const uint8_t* sH2 = sHb + (cur * 2 + 1) * TH * TW + q * TW;
+        const int r = rbase + SP * (TH * ty + q);
+        {
+            const uint16_t* rowbase = sT + (SP * q) * RS;             // window row of image row r - 5
+            const char* tap[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(rowbase + off[ch]);
+#define RAISR_PAIR(p, ds) (*reinterpret_cast<const unsigned*>((p) + 16 * (ds)))      /* step ds: +8 samples */
+            float keep = 0.0f;
+            const bool anyB = sH2[lane] != 0xFFu;
+            // the 16 buckets of the lane group's pixels, two per step (m = 8 ds + 2 g + e)
+            unsigned hp[8];
+#pragma unroll
+            for (int ds = 0; ds < 8; ds++) hp[ds] = *reinterpret_cast<const uint16_t*>(sH + 8 * ds + 2 * g);
+            // "virtual step" vs = 2 ds + e covers pixels m(vs, g); as in filter_phase the 16 virtual steps go in four groups
+            // {j, j+4, j+8, j+12}: two DPP levels per accumulator, the four partial sums merged quad-wise, the last two levels,
+            // the accept test and the keep-select once per group.  Steps ds = 0,2,4,6 feed groups 0 and 1, ds = 1,3,5,7 groups 2 and 3.
+            const uint16_t* ctrrow = rowbase + 5 * RS + ((5 % SP) ? REG2 : REG0) + 5 / SP + 2 * g;
+#pragma unroll
+            for (int ph = 0; ph < 2; ph++) {
+                float part0[4], part1[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    const int ds = 2 * mm + ph;
+                    const unsigned h0 = min(hp[ds] & 0xFFu, 216u), h1 = min(hp[ds] >> 8, 216u);
+                    const float4 fa0 = *reinterpret_cast<const float4*>(sBank + h0 * 128u + (unsigned)l * 4u);
+                    const float4 fb0 = *reinterpret_cast<const float4*>(sBank + h0 * 128u + 64u + (unsigned)l * 4u);
+                    const float4 fa1 = *reinterpret_cast<const float4*>(sBank + h1 * 128u + (unsigned)l * 4u);
+                    const float4 fb1 = *reinterpret_cast<const float4*>(sBank + h1 * 128u + 64u + (unsigned)l * 4u);
+                    unsigned pw[8];
+#pragma unroll
+                    for (int ch = 0; ch < 8; ch++) pw[ch] = RAISR_PAIR(tap[ch], ds);
+                    // acc = p[l] * f[l] is fma(p, f, -0) bit for bit; then the seven explicit fmadds of DotProdPatch
+                    float a0 = fma_mix_lo(pw[0], fa0.x, negzero), a1 = fma_mix_hi(pw[0], fa1.x, negzero);
+                    a0 = fma_mix_lo(pw[1], fa0.y, a0); a1 = fma_mix_hi(pw[1], fa1.y, a1);
+                    a0 = fma_mix_lo(pw[2], fa0.z, a0); a1 = fma_mix_hi(pw[2], fa1.z, a1);
+                    a0 = fma_mix_lo(pw[3], fa0.w, a0); a1 = fma_mix_hi(pw[3], fa1.w, a1);
+                    a0 = fma_mix_lo(pw[4], fb0.x, a0); a1 = fma_mix_hi(pw[4], fb1.x, a1);
+                    a0 = fma_mix_lo(pw[5], fb0.y, a0); a1 = fma_mix_hi(pw[5], fb1.y, a1);
+                    a0 = fma_mix_lo(pw[6], fb0.z, a0); a1 = fma_mix_hi(pw[6], fb1.z, a1);
+                    a0 = fma_mix_lo(pw[7], fb0.w, a0); a1 = fma_mix_hi(pw[7], fb1.w, a1);
+                    a0 = a0 + row_ror<0x128>(a0); part0[mm] = a0 + row_ror<0x124>(a0);
+                    a1 = a1 + row_ror<0x128>(a1); part1[mm] = a1 + row_ror<0x124>(a1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int j = 2 * ph + e;                          // group j: virtual steps j, j+4, j+8, j+12 <-> quads 0..3
+                    float v = e ? part1[0] : part0[0];
+                    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(e ? part1[1] : part0[1]), "s"(0x00f000f000f000f0ull));
+                    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(e ? part1[2] : part0[2]), "s"(0x0f000f000f000f00ull));
+                    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(e ? part1[3] : part0[3]), "s"(0xf000f000f000f000ull));
+                    v = v + quad_perm<0x4e>(v);
+                    v = v + quad_perm<0xb1>(v);
+                    // this lane's quad (l >> 2) ends up with virtual step j + 4 (l >> 2): its centre pixel m = 8 (vs >> 1) + 2 g + (vs & 1)
+                    const int vsq = j + 4 * (l >> 2);
+                    float res = (float)__builtin_bit_cast(_Float16, ctrrow[8 * (vsq >> 1) + (vsq & 1)]);
+                    if (v > P.lo && v < P.hi) res = v;
+                    // lane (g, l) keeps virtual step l: in group j those are the lanes with (l & 3) == j
+                    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
+                }
+            }
+            if (__any(anyB)) {                                       // tail columns: AVX2 re-hash (keep-first-if-rejected)
+#pragma unroll 1
+                for (int ds = 0; ds < 8; ds++) {
+                    const unsigned b0 = sH2[8 * ds + 2 * g], b1 = sH2[8 * ds + 2 * g + 1];
+                    if (b0 == 0xFFu && b1 == 0xFFu) continue;
+                    const unsigned h0 = min(b0, 216u), h1 = min(b1, 216u);
+                    const float4 fa0 = *reinterpret_cast<const float4*>(sBank + h0 * 128u + (unsigned)l * 4u);
+                    const float4 fb0 = *reinterpret_cast<const float4*>(sBank + h0 * 128u + 64u + (unsigned)l * 4u);
+                    const float4 fa1 = *reinterpret_cast<const float4*>(sBank + h1 * 128u + (unsigned)l * 4u);
+                    const float4 fb1 = *reinterpret_cast<const float4*>(sBank + h1 * 128u + 64u + (unsigned)l * 4u);
+                    unsigned pw[8];
+#pragma unroll
+                    for (int ch = 0; ch < 8; ch++) pw[ch] = RAISR_PAIR(tap[ch], ds);
+                    float a0 = fma_mix_lo(pw[0], fa0.x, negzero), a1 = fma_mix_hi(pw[0], fa1.x, negzero);
+                    a0 = fma_mix_lo(pw[1], fa0.y, a0); a1 = fma_mix_hi(pw[1], fa1.y, a1);
+                    a0 = fma_mix_lo(pw[2], fa0.z, a0); a1 = fma_mix_hi(pw[2], fa1.z, a1);
+                    a0 = fma_mix_lo(pw[3], fa0.w, a0); a1 = fma_mix_hi(pw[3], fa1.w, a1);
+                    a0 = fma_mix_lo(pw[4], fb0.x, a0); a1 = fma_mix_hi(pw[4], fb1.x, a1);
+                    a0 = fma_mix_lo(pw[5], fb0.y, a0); a1 = fma_mix_hi(pw[5], fb1.y, a1);
+                    a0 = fma_mix_lo(pw[6], fb0.z, a0); a1 = fma_mix_hi(pw[6], fb1.z, a1);
+                    a0 = fma_mix_lo(pw[7], fb0.w, a0); a1 = fma_mix_hi(pw[7], fb1.w, a1);
+                    const float v0 = tree16(a0), v1 = tree16(a1);
+                    const uint16_t* cp = rowbase + 5 * RS + ((5 % SP) ? REG2 : REG0) + 5 / SP + 8 * ds + 2 * g;
+                    if (l == 2 * ds && b0 != 0xFFu) {
+                        if (v0 > P.lo && v0 < P.hi) keep = v0;
+                        else if (P.randomness) keep = (float)__builtin_bit_cast(_Float16, cp[0]);
+                    }
+                    if (l == 2 * ds + 1 && b1 != 0xFFu) {
+                        if (v1 > P.lo && v1 < P.hi) keep = v1;
+                        else if (P.randomness) keep = (float)__builtin_bit_cast(_Float16, cp[1]);
+                    }
+                }
+            }
+#undef RAISR_PAIR
+            const int m = 8 * (l >> 1) + 2 * g + (l & 1);
+            const int c = cbase + SP * (TW * tx + m);
+            if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
+        }
+        if (nxt < ntiles) stash(cur ^ 1);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_blend (CountOfBitsChanged): CTCountOfBitsChangedSegment_AVX256_32f, Raisr_AVX256.cpp:68-166,
 // plus the border policy of processSegment (Raisr.cpp:999-1028,1252-1265): row 0, row H-1, col 0,
@@ -1919,6 +2154,7 @@ struct raisr_hip_ctx {
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
+    bool lds16 = true;                         // binary16 LR window + two pixels per lane (8/10-bit content); RAISR_HIP_LDS16=0: fp32 window
     int n_cus = 256;                           // persistent k_filter_lds grid: one workgroup per CU (multiple of 4)
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
     FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
@@ -2074,10 +2310,18 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 const bool sp2 = P.pixel_types == 4;
                 const int wh = sp2 ? 41 : 26, lw = sp2 ? 141 : 77;
                 const size_t shmem = (size_t)217 * 128 * 4 + 2 * (size_t)wh * lw * 4 + 4 * 1024;
+                if (c->cfg.bits <= 10 && c->lds16) {
+                    const size_t sh16 = (size_t)217 * 128 * 4 + 2 * (size_t)wh * (sp2 ? 286 : 154) * 2 + 4 * 1024;
+                    timer_begin(c, "k_filter_lds16", s, slot);
+                    if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                    else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                    timer_end(c, s, slot);
+                } else {
                 timer_begin(c, "k_filter_lds", s, slot);
                 if (sp2) hipLaunchKernelGGL((k_filter_lds<TOut, 2>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 else hipLaunchKernelGGL((k_filter_lds<TOut, 1>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
+                }
             } else {
                 timer_begin(c, "k_filter", s, slot);
                 hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
@@ -2278,6 +2522,7 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
+    if (const char* e = getenv("RAISR_HIP_LDS16")) c->lds16 = atoi(e) != 0;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 4) c->n_cus = prop.multiProcessorCount & ~3;
@@ -2286,6 +2531,10 @@ static int create_impl(raisr_hip_ctx* c)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     }
     HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
     if (const char* e = getenv("RAISR_HIP_PHASES")) if (atoi(e)) {
