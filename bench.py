@@ -302,40 +302,65 @@ def end_to_end_leg(R, wl, n_frames, gpu):
             "what": "host->host yuv420p through RNLHandler_Process (synchronous, pageable caller planes, Y+U+V, PCIe inclusive)"}
 
 
-def stream_leg(R, wl, gpu, n_frames, check_against=None):
-    """Host planes -> host planes through the library's pinned ring (raisr_hip_stream_*): uploads, kernels and downloads of
-    neighbouring frames overlap.  Returns the JSON object and the output planes of the first `len(check_against)` frames."""
+def stream_leg(R, wl, gpu, n_frames, collect_outputs=0):
+    """Host planes -> host planes through the library's ring (raisr_hip_stream_*): uploads, kernels and downloads of
+    neighbouring frames overlap.  The planes are page-locked (raisr_hip_host_alloc), as a host with its own buffer pool would
+    hand them over.  Returns the JSON object (and, for tests, copies of the first `collect_outputs` Y outputs)."""
     import synth
-    ys = wl.frames("natural", range(4))
+    ys_np = wl.frames("natural", range(4))
     cw, ch = wl.in_w // 2, wl.in_h // 2
     ratio = wl.out_w / wl.in_w
-    u = synth.chroma(cw, ch, wl.bits)
+    ocw, och = int(cw * ratio), int(ch * ratio)
+    depth = 4
+    dt = ys_np[0].dtype
+    pins = []
+
+    def pinned(shape, fill=None):
+        pl = R.PinnedPlane(shape, dt)
+        pins.append(pl)
+        if fill is not None:
+            pl.array[...] = fill
+        return pl.array
+    ys = [pinned(y.shape, y) for y in ys_np]
+    u = pinned((ch, cw), synth.chroma(cw, ch, wl.bits))
+    frames_out = [R.PinnedFrame(wl.out_w, wl.out_h, ocw, och, wl.bits) for _ in range(depth)]     # packed: one D2H copy per frame
+    pins.extend(frames_out)
+    outs = [(f.y, f.u, f.v) for f in frames_out]
     st = R.RaisrStream(gpu, wl.folder, wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode,
-                       hash_variant=wl.asm, chroma=(cw, ch, int(cw * ratio), int(ch * ratio)), depth=4)
-    outs = [(np.zeros((wl.out_h, wl.out_w), ys[0].dtype), np.zeros((int(ch * ratio), int(cw * ratio)), u.dtype),
-             np.zeros((int(ch * ratio), int(cw * ratio)), u.dtype)) for _ in range(st.depth)]
+                       hash_variant=wl.asm, chroma=(cw, ch, ocw, och), depth=depth)
+    kept = []
     try:
         for warm in (True, False):
             n = 8 if warm else n_frames
             t0 = time.perf_counter()
             inflight = 0
+            done = 0
             for i in range(n):
-                if inflight == st.depth:
+                if inflight == depth:
                     st.collect()
+                    if not warm and done < collect_outputs:
+                        kept.append(outs[done % depth][0].copy())
+                    done += 1
                     inflight -= 1
-                oy, ou, ov = outs[i % st.depth]
+                oy, ou, ov = outs[i % depth]
                 st.submit(ys[i % 4], u, u, oy, ou, ov)
                 inflight += 1
             while inflight:
                 st.collect()
+                if not warm and done < collect_outputs:
+                    kept.append(outs[done % depth][0].copy())
+                done += 1
                 inflight -= 1
-            dt = time.perf_counter() - t0
+            dt_s = time.perf_counter() - t0
     finally:
         st.close()
-    fps = n_frames / dt
-    return {"value": round(fps * wl.out_w * wl.out_h / 1e6, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
-            "what": f"host->host yuv420p through the pinned-ring batch entry (depth {st.depth}: H2D of frame n+1 and D2H of frame n-1 "
-                    "overlap frame n's kernels; Y+U+V, PCIe inclusive)"}
+        for pl in pins:
+            pl.close()
+    fps = n_frames / dt_s
+    res = {"value": round(fps * wl.out_w * wl.out_h / 1e6, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
+           "what": f"host->host yuv420p through the stream ring (depth {depth}: H2D of frame n+1 and D2H of frame n-1 overlap frame n's "
+                   "kernels; page-locked planes, Y+U+V, PCIe inclusive)"}
+    return (res, kept) if collect_outputs else res
 
 
 def parity_leg(R, wl, gpu, blobs, kind):
@@ -425,17 +450,15 @@ def main():
     timing = not args.no_kernel_timing and not args.stream
     kern, iso = {}, {}
     if args.stream:
-        # host-resident frames of the (virtual) stream, frame i -> rank i mod world, through the pinned ring
-        mine = sharding.frames_for_rank(nf * world, rank, world)
+        # host-resident frames of the (virtual) stream, frame i -> rank i mod world, through the stream ring; the timed
+        # region is the submit/collect loop over this rank's frames of all K steps (ring and page-locked planes set up outside)
+        mine = sharding.frames_for_rank(nf * args.steps * world, rank, world)
         fence()
-        t0 = time.perf_counter()
-        res = None
-        for _ in range(args.steps):
-            res = stream_leg(R, wl, gpu, len(mine))
+        res = stream_leg(R, wl, gpu, len(mine))
+        dt = len(mine) / res["fps"]
         fence()
-        dt = time.perf_counter() - t0
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
-        frames_total = len(mine) * world * args.steps
+        frames_total = len(mine) * world
         lanes = []
     else:
         uniq = min(nf, 8)

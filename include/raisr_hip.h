@@ -114,6 +114,10 @@ int raisr_hip_process_host(raisr_hip_ctx *ctx,
                            const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
                            const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
                            int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h);
+/* Layout of a PACKED host frame: Y, U, V with tight pitches at offsets[0..2] (256-byte aligned plane starts), total size
+ * *total_bytes.  When the three output planes handed to raisr_hip_process_host* / raisr_hip_stream_submit lie like this in
+ * one allocation, the frame is downloaded as a single PCIe copy instead of three. */
+int raisr_hip_packed_frame_layout(int y_w, int y_h, int c_w, int c_h, int bits, size_t offsets[3], size_t *total_bytes);
 int raisr_hip_synchronize(raisr_hip_ctx *ctx);   /* waits for everything the context has enqueued (Y and chroma lanes) */
 
 /* Horizontal bands ----------------------------------------------------------------------------
@@ -150,6 +154,31 @@ int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
                                  const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
                                  int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h,
                                  const raisr_hip_rows *rows);
+
+/* Streamed host pipeline ---------------------------------------------------------------------
+ * A ring of `depth` contexts: submit() enqueues frame n's upload, kernels and download on lane n % depth and returns;
+ * collect() waits for the oldest frame.  With page-locked planes (raisr_hip_host_alloc, or the caller's own buffers
+ * through raisr_hip_host_register) frame n+1's upload and frame n-1's download overlap frame n's kernels; pageable planes
+ * work too, without the overlap (the runtime stages them on the calling thread).  This is the batch entry beside the
+ * synchronous RNLProcess (Library/Raisr.cpp:1294-1397), which keeps its one-frame contract.  One thread drives a stream. */
+typedef struct raisr_hip_stream raisr_hip_stream;
+int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..16 */
+void raisr_hip_stream_destroy(raisr_hip_stream *s);
+int  raisr_hip_stream_depth(const raisr_hip_stream *s);
+int  raisr_hip_stream_set_model(raisr_hip_stream *s, int pass_index, const float *bank, int hashkeys, int pixel_types,
+                                const double qstr[2], const double qcoh[2], int quant_angle);
+int  raisr_hip_stream_configure(raisr_hip_stream *s, const raisr_hip_config *cfg);
+int  raisr_hip_stream_submit(raisr_hip_stream *s,
+                             const void *in_y, size_t in_y_pitch, void *out_y, size_t out_y_pitch,
+                             const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
+                             const void *in_v, size_t in_v_pitch, void *out_v, size_t out_v_pitch,
+                             int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h);
+int  raisr_hip_stream_collect(raisr_hip_stream *s);
+int  raisr_hip_stream_in_flight(const raisr_hip_stream *s);
+void *raisr_hip_host_alloc(size_t bytes);            /* page-locked host memory for frame planes */
+void raisr_hip_host_free(void *p);
+int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns */
+int  raisr_hip_host_unregister(void *p);
 
 /* Introspection for tests / profiling ---------------------------------------------------------
  * Copies the last frame's per-pixel hash plane (u8: bucket 0..215 of the first hash, stale outside the

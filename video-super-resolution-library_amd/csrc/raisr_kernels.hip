@@ -2183,6 +2183,7 @@ struct raisr_hip_ctx {
     GaussW gauss{};
     // device staging for raisr_hip_process_host
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    hipEvent_t ev_chroma = nullptr;             // chroma lane done (packed-frame download waits for it)
     KernelTimer timer;
 };
 
@@ -2598,6 +2599,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
     if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
+    if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
     if (c->d_gauss) (void)hipFree(c->d_gauss);
     if (c->d_prof) {
         unsigned long long h[16];
@@ -2986,12 +2988,37 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         }
     }
     if (do_down) {
-        if (chroma && c_keep > 0) {
-            HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
-            HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+        // Packed output frame: when the caller's three output planes sit in host memory exactly as the staging planes sit in
+        // device memory (raisr_hip_packed_frame_layout), the whole frame goes back as ONE copy -- fewer, larger PCIe
+        // transfers (the download is what bounds a streamed 4K job: 12.4 MB per frame).
+        const bool packed = chroma && !rows && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
+                            (const char*)out_u == (const char*)out_y + (off_ou - off_oy) && (const char*)out_v == (const char*)out_y + (off_ov - off_oy);
+        if (packed) {
+            if (!c->ev_chroma) HIP_TRY(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->ev_chroma, s2));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_chroma, 0));
+            HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, s));
+        } else {
+            if (chroma && c_keep > 0) {
+                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            }
+            if (y_keep > 0) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
         }
-        if (y_keep > 0) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
     }
+    return RAISR_HIP_OK;
+}
+
+// Byte offsets of the Y, U and V planes of a packed frame (tight pitches; each plane starts on a 256-byte boundary) and its
+// total size: the host-side layout raisr_hip_process_host* recognises and downloads (uploads) as one copy.
+int raisr_hip_packed_frame_layout(int y_w, int y_h, int c_w, int c_h, int bits, size_t offsets[3], size_t* total_bytes)
+{
+    if (y_w <= 0 || y_h <= 0 || c_w < 0 || c_h < 0 || !offsets || !total_bytes) return fail(RAISR_HIP_EINVAL, "bad argument");
+    const size_t bps = bits == 8 ? 1 : 2;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t ny = (size_t)y_w * y_h * bps, nc = (size_t)c_w * c_h * bps;
+    offsets[0] = 0; offsets[1] = al(ny); offsets[2] = offsets[1] + al(nc);
+    *total_bytes = offsets[2] + nc;
     return RAISR_HIP_OK;
 }
 

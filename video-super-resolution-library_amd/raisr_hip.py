@@ -104,6 +104,23 @@ def lib():
         L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.raisr_hip_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_stream_destroy.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_stream_destroy.restype = None
+        L.raisr_hip_stream_depth.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_stream_set_model.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_stream_configure.argtypes = [ctypes.c_void_p, ctypes.POINTER(RaisrHipConfig)]
+        L.raisr_hip_stream_submit.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
+        L.raisr_hip_stream_collect.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_stream_in_flight.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_host_alloc.argtypes = [ctypes.c_size_t]
+        L.raisr_hip_host_alloc.restype = ctypes.c_void_p
+        L.raisr_hip_host_free.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_host_free.restype = None
+        L.raisr_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.raisr_hip_host_unregister.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -349,3 +366,105 @@ class RaisrDevice:
             nm = names.raw[64 * i:64 * (i + 1)].split(b"\0")[0].decode()
             out[nm] = {"total_ms": float(ms[i]), "count": int(cnt[i])}
         return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Streamed host pipeline (raisr_hip_stream_*): ring of contexts, page-locked planes
+# ----------------------------------------------------------------------------------------------
+class PinnedPlane:
+    """A 2-D numpy array over page-locked host memory from raisr_hip_host_alloc (freed on close / garbage collection)."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().raisr_hip_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("raisr_hip_host_alloc failed")
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().raisr_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedFrame:
+    """Y, U, V planes of one frame in ONE page-locked allocation laid out as raisr_hip_packed_frame_layout says: the library
+    moves such a frame with a single PCIe copy."""
+
+    def __init__(self, y_w, y_h, c_w, c_h, bits):
+        offs = (ctypes.c_size_t * 3)(); total = ctypes.c_size_t()
+        _check(lib().raisr_hip_packed_frame_layout(y_w, y_h, c_w, c_h, bits, offs, ctypes.byref(total)), "packed_frame_layout")
+        dt = np.uint8 if bits == 8 else np.uint16
+        self._blk = PinnedPlane((total.value,), np.uint8)
+        raw = self._blk.array
+        isz = np.dtype(dt).itemsize
+        self.y = raw[offs[0]:offs[0] + y_w * y_h * isz].view(dt).reshape(y_h, y_w)
+        self.u = raw[offs[1]:offs[1] + c_w * c_h * isz].view(dt).reshape(c_h, c_w)
+        self.v = raw[offs[2]:offs[2] + c_w * c_h * isz].view(dt).reshape(c_h, c_w)
+
+    def close(self):
+        self.y = self.u = self.v = None
+        self._blk.close()
+
+
+class RaisrStream:
+    """depth frames in flight through one GPU: submit() enqueues, collect() waits for the oldest frame."""
+
+    def __init__(self, device, folder, in_w, in_h, out_w, out_h, bits=8, full_range=False, passes=1, mode=1,
+                 hash_variant=HASH_AVX512, blending=BLEND_COUNT, chroma=None, depth=4, tie=TIE_HALF_UP):
+        self._h = ctypes.c_void_p()
+        _check(lib().raisr_hip_stream_create(ctypes.byref(self._h), device, depth), "raisr_hip_stream_create")
+        self.depth = depth
+        try:
+            for p in range(passes):
+                bank, qstr, qcoh, qa = read_model_folder(folder, bits, p + 1)
+                bank = np.ascontiguousarray(bank, np.float32)
+                qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
+                hk, pt, _ = bank.shape
+                _check(lib().raisr_hip_stream_set_model(self._h, p, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data, qa),
+                       "raisr_hip_stream_set_model")
+            lo, hi = clamp_range(bits, full_range)
+            c = RaisrHipConfig()
+            c.in_width, c.in_height, c.out_width, c.out_height = in_w, in_h, out_w, out_h
+            c.bits, c.clamp_lo, c.clamp_hi = bits, lo, hi
+            c.passes, c.two_pass_mode = passes, mode
+            c.hash_variant, c.blending = hash_variant, blending
+            c.use_pixel_type = int(out_w == 2 * in_w and out_h == 2 * in_h)
+            c.tie_rule = tie
+            _check(lib().raisr_hip_stream_configure(self._h, ctypes.byref(c)), "raisr_hip_stream_configure")
+        except Exception:
+            self.close()
+            raise
+        self.chroma = chroma            # (in_w, in_h, out_w, out_h) of each chroma plane, or None
+
+    def submit(self, y, u, v, oy, ou, ov):
+        def pp(a):
+            return (a.ctypes.data, a.strides[0]) if a is not None else (None, 0)
+        cw, ch, ocw, och = self.chroma if (self.chroma and u is not None) else (0, 0, 0, 0)
+        _check(lib().raisr_hip_stream_submit(self._h, *pp(y), *pp(oy), *pp(u), *pp(ou), *pp(v), *pp(ov), cw, ch, ocw, och),
+               "raisr_hip_stream_submit")
+
+    def collect(self):
+        _check(lib().raisr_hip_stream_collect(self._h), "raisr_hip_stream_collect")
+
+    def in_flight(self):
+        return lib().raisr_hip_stream_in_flight(self._h)
+
+    def close(self):
+        if self._h:
+            lib().raisr_hip_stream_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
