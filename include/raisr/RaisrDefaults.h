@@ -26,7 +26,11 @@ typedef enum ASMType {
     OpenCL         = 3,   /* rejected: no OpenCL in this build                          */
     OpenCLExternal = 4,   /* rejected                                                   */
     AVX512_FP16    = 5,   /* AVX512-FP16 path's output (binary16 pipeline, 8-bit only)  */
-    HIP            = 6    /* appended: MI355X backend, AVX-512 fp32 numerics            */
+    HIP            = 6,   /* appended: MI355X backend, AVX-512 fp32 numerics            */
+    HIPExternal    = 7    /* appended: as HIP, but every VideoDataType::pData handed to SetRes / Process is a HIP
+                           * DEVICE pointer (step = device pitch in bytes): frames that are already in HBM (hardware
+                           * decode, a previous GPU filter) are processed in place -- the counterpart of the reference's
+                           * OpenCLExternal / vf_raisr_opencl.c zero-copy path (ffmpeg/vf_raisr_opencl.c:50-150)      */
 } ASMType;
 
 /* ---- sample range: VideoRange clamps to [16,235]<<(bits-8), FullRange to [0,2^bits-1] -------- */
@@ -50,7 +54,7 @@ typedef enum MachineVendorType {
 
 /* ---- one image plane; `step` = bytes between rows (may exceed width * bytes per sample) ------ */
 typedef struct VideoDataType {
-    unsigned char *pData;      /* host pointer, caller-owned                                     */
+    unsigned char *pData;      /* host pointer, caller-owned (a HIP device pointer with asm = HIPExternal) */
     unsigned int   width;      /* samples per row                                                */
     unsigned int   height;     /* rows                                                           */
     unsigned int   step;

@@ -8,7 +8,10 @@
  *   SetRes   once, with the first frame's plane descriptors (sizes/steps only)
  *   Process  per frame, synchronous; caller owns every buffer; host planes in, host planes out
  *   SetOpenCLContext(NULL, NULL, platform, device): kept as the device-selection hook --
- *            `deviceOrdinal` is the HIP device ordinal; call before Init
+ *            `deviceOrdinal` is the HIP device ordinal; call before Init.
+ *            With asm = HIPExternal (device-pointer planes) `clContext` may carry the caller's hipStream_t: Process then
+ *            enqueues on that stream and returns without waiting (stream-ordered, like the reference's external OpenCL
+ *            queue); with clContext == NULL Process waits for the frame before it returns.
  *   Deinit   releases device and host resources
  */
 #ifndef RAISR_HANDLER_H

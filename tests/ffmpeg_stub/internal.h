@@ -1,0 +1,3 @@
+#pragma once
+#include "avfilter.h"
+int ff_filter_frame(AVFilterLink *link, AVFrame *frame);

@@ -1,0 +1,39 @@
+"""CPU: the FFmpeg deliverables (ffmpeg/).  vf_raisr_hip.diff must apply to the reference's vf_raisr.c (only available in
+the build container: skipped elsewhere), and the patched filter must pass `gcc -fsyntax-only` against the library's own
+headers plus a declaration-only lint subset of the libavfilter API (tests/ffmpeg_stub/)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/ffmpeg/vf_raisr.c"
+
+
+def test_build_system_patch_mentions_every_touch_point():
+    s = open(os.path.join(ROOT, "ffmpeg", "0001-ffmpeg-raisr-hip-filter.patch")).read()
+    for needle in ("--enable-libraisr", "raisr_filter_deps=\"libraisr\"", "-lraisr_hip -lamdhip64 -lstdc++", "RNLHandler_Init",
+                   "OBJS-$(CONFIG_RAISR_FILTER)", "extern const AVFilter ff_vf_raisr;"):
+        assert needle in s, needle
+    assert "libipp" not in s                        # the CPU library's IPP dependency is gone
+
+
+@pytest.mark.skipif(not os.path.exists(REF) or shutil.which("patch") is None, reason="needs the reference tree and patch(1)")
+def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_path):
+    work = tmp_path / "libavfilter"
+    work.mkdir()
+    shutil.copy(REF, work / "vf_raisr.c")
+    diff = os.path.join(ROOT, "ffmpeg", "vf_raisr_hip.diff")
+    dry = subprocess.run(["patch", "--dry-run", "-p1", "-d", str(work), "-i", diff], capture_output=True, text=True)
+    assert dry.returncode == 0, dry.stdout + dry.stderr
+    real = subprocess.run(["patch", "-p1", "-d", str(work), "-i", diff], capture_output=True, text=True)
+    assert real.returncode == 0, real.stdout + real.stderr
+    src = (work / "vf_raisr.c").read_text()
+    assert 'asm_t = HIP;' in src and '{.str = "hip"}' in src
+    assert "if (asm_t == OpenCL)" not in src        # the device hook now runs for every asm value
+    cc = shutil.which("gcc") or shutil.which("cc")
+    out = subprocess.run([cc, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wno-unused-variable", "-Wno-declaration-after-statement",
+                          "-I", os.path.join(ROOT, "tests", "ffmpeg_stub"), "-I", os.path.join(ROOT, "include"),
+                          str(work / "vf_raisr.c")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]

@@ -111,3 +111,47 @@ def test_border_policy_full_size_c2():
     assert np.array_equal(out[:, 0], lr[:, 0]) and np.array_equal(out[:, -1], lr[:, -1])
     assert np.array_equal(out[1:6, 1:-1], clip[1:6, 1:-1]) and np.array_equal(out[-6:-1, 1:-1], clip[-6:-1, 1:-1])
     assert np.array_equal(out[1:-1, 1:6], clip[1:-1, 1:6]) and np.array_equal(out[1:-1, 3830:-1], clip[1:-1, 3830:-1])
+
+
+def test_c5_600_frame_stream_every_frame_equals_the_oracle():
+    """BASELINE config 5's defining property on one GPU: a 600-frame 4K->8K 10-bit stream through the streamed host
+    pipeline (the per-rank loop of `bench.py --config C5 --stream`).  The stream cycles over 3 distinct synthetic frames;
+    every one of the 600 outputs must equal the oracle's output for its input, in order."""
+    import raisr_hip as R
+    import synth
+    case = BASELINE[4]
+    w, h = case[8]
+    uniq, n, depth = 3, 600, 3
+    ys = [synth.natural_y(w, h, 10, seed=12345 + i) for i in range(uniq)]
+    refs = [oracle_y(y, case[:8]) for y in ys]
+    cw, ch = w // 2, h // 2
+    c = synth.chroma(cw, ch, 10)
+    pins = [R.PinnedPlane(y.shape, np.uint16) for y in ys] + [R.PinnedPlane(c.shape, np.uint16)]
+    for pl, src in zip(pins, ys + [c]):
+        pl.array[...] = src
+    fout = [R.PinnedFrame(2 * w, 2 * h, 2 * cw, 2 * ch, 10) for _ in range(depth)]
+    st = R.RaisrStream(0, folder(case[1]), w, h, 2 * w, 2 * h, bits=10, chroma=(cw, ch, 2 * cw, 2 * ch), depth=depth)
+    bad = []
+    try:
+        done = inflight = 0
+
+        def collect():
+            nonlocal done, inflight
+            st.collect()
+            if not np.array_equal(fout[done % depth].y, refs[done % uniq]) or not np.all(fout[done % depth].u == 512):
+                bad.append(done)
+            fout[done % depth].y[0, :8] = 0                      # stale bytes must not survive into the lane's next frame
+            done += 1; inflight -= 1
+        for i in range(n):
+            if inflight == depth:
+                collect()
+            f = fout[i % depth]
+            st.submit(pins[i % uniq].array, pins[uniq].array, pins[uniq].array, f.y, f.u, f.v)
+            inflight += 1
+        while inflight:
+            collect()
+    finally:
+        st.close()
+        for p in pins + fout:
+            p.close()
+    assert done == n and not bad, bad[:10]

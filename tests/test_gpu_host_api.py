@@ -250,3 +250,56 @@ def test_16bit_depth_against_the_oracle(tmp_path, passes, mode):
     oy, _, _ = R.upscale_frame_host(frames["random"], c, c, str(dst), ratio=2.0, bits=16, range_type=R.FullRange, asm_type=R.AVX512,
                                     passes=passes, mode=mode)
     assert np.array_equal(oy, oracle_y(frames["random"], ("x", str(dst), (2, 1), 16, passes, mode, 2, True)))
+
+
+@pytest.mark.parametrize("bits,passes,use_stream", [(8, 1, False), (10, 2, False), (8, 1, True)])
+def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream):
+    """asm = HIPExternal (RaisrDefaults.h): SetRes / Process take DEVICE pointers (pitched planes) -- the zero-copy
+    counterpart of vf_raisr_opencl.c.  Output compared with the oracle (Y) and the oracle's cheap upscale (chroma)."""
+    import ctypes
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    import torch
+    w, h = 176, 100
+    fold = "filters_2x/filters_highres"
+    tdt = torch.uint8 if bits == 8 else torch.uint16
+    ndt = np.uint8 if bits == 8 else np.uint16
+    bps = 1 if bits == 8 else 2
+    y = synth.natural_y(w, h, bits, seed=21)
+    u = synth.random_y(w // 2, h // 2, bits, seed=22).astype(ndt)
+    v = synth.random_y(w // 2, h // 2, bits, seed=23).astype(ndt)
+
+    def dev_plane(a, pad):                                  # pitched device plane holding `a`
+        host = np.zeros((a.shape[0], a.shape[1] + pad), ndt)
+        host[:, :a.shape[1]] = a
+        return torch.from_numpy(host.view(np.int16) if bits != 8 else host).cuda().view(tdt)
+
+    def vdt(t, width, height):
+        d = R.VideoDataType()
+        d.pData = t.data_ptr(); d.width = width; d.height = height; d.step = t.stride(0) * bps; d.bitShift = 0
+        return d
+    dy, du, dv = dev_plane(y, 16), dev_plane(u, 8), dev_plane(v, 8)
+    oy = torch.zeros((2 * h, 2 * w + 32), dtype=tdt, device="cuda")
+    ou = torch.zeros((h, w + 16), dtype=tdt, device="cuda")
+    ov = torch.zeros((h, w + 16), dtype=tdt, device="cuda")
+    ds = [vdt(dy, w, h), vdt(du, w // 2, h // 2), vdt(dv, w // 2, h // 2), vdt(oy, 2 * w, 2 * h), vdt(ou, w, h), vdt(ov, w, h)]
+    refs = [ctypes.byref(x) for x in ds]
+    stream = torch.cuda.Stream() if use_stream else None
+    assert R.RNLHandler_SetOpenCLContext(0, 0, stream.cuda_stream if stream else None) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, bits, R.VideoRange, 20, R.HIPExternal, passes, 1) == 0
+    try:
+        torch.cuda.synchronize()
+        assert R.lib().RNLHandler_SetRes(*refs) == 0
+        for _ in range(2):
+            assert R.lib().RNLHandler_Process(*refs, R.CountOfBitsChanged) == 0
+        if stream:
+            stream.synchronize()                           # stream-ordered: the caller's stream carries the work
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+        R.RNLHandler_SetOpenCLContext(0, 0, None)
+    got_y = oy[:, :2 * w].cpu().numpy().view(ndt)
+    ref = oracle_y(y, ("x", fold, (2, 1), bits, passes, 1, 2, False))
+    assert np.array_equal(got_y, ref)
+    assert np.array_equal(ou[:, :w].cpu().numpy().view(ndt), O.resize(u, w, h).astype(ndt))
+    assert np.array_equal(ov[:, :w].cpu().numpy().view(ndt), O.resize(v, w, h).astype(ndt))

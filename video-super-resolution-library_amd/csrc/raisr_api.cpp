@@ -53,6 +53,8 @@ struct State {
     // plane geometry RNLSetRes configured: RNLProcess refuses frames that differ (the copies are asynchronous DMAs)
     unsigned geo[6][2] = {};                      // {width, height} of inY, inCr, inCb, outY, outCr, outCb
     bool deviceChosen = false;                    // RNLSetOpenCLContext named a device; otherwise RAISR_HIP_DEVICE / 0
+    bool external = false;                        // asm = HIPExternal: plane pointers are device pointers
+    void *externalStream = nullptr;               // caller's hipStream_t for external frames (NULL: own stream + wait)
 } G;
 
 // ---- config / trained-data parsing -------------------------------------------------------------
@@ -265,6 +267,7 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
     G.bitDepth = bitDepth;
 
     // asm mapping: which x86 path's output the GPU reproduces (DESIGN.md "asm mapping")
+    G.external = (int)asmType == HIPExternal;
     switch ((int)asmType) {
     case AVX2:
         G.hashVariant = RAISR_HIP_HASH_AVX2;
@@ -283,6 +286,10 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
             G.hashVariant = RAISR_HIP_HASH_AVX512;
             std::cout << "ASM Type: HIP gfx950 (AVX512-exact numerics)\n";
         }
+        break;
+    case HIPExternal:
+        G.hashVariant = RAISR_HIP_HASH_AVX512;
+        std::cout << "ASM Type: HIP gfx950 (AVX512-exact numerics), device-resident frames\n";
         break;
     default:   // AVX512, HIP and out-of-range values (the reference also falls back to its best path)
         G.hashVariant = RAISR_HIP_HASH_AVX512;
@@ -360,7 +367,7 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
     // band plan: luma with the pass count's padding, chroma (cheap upscale only) with its own
     dropExtraBands();
     G.resSet = false;
-    const int want = wantedBands(cfg.out_height);
+    const int want = G.external ? 1 : wantedBands(cfg.out_height);
     std::vector<raisr_hip_band> yb((size_t)want), cb((size_t)want);
     int K = want > 1 ? raisr_hip_plan_bands(cfg.in_height, cfg.out_height, cfg.passes, want, yb.data()) : 1;
     if (K < 1) K = 1;
@@ -421,6 +428,16 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         return RNLErrorUndefined;
     };
     const size_t K = G.yBands.size();
+    if (G.external) {
+        // planes are device pointers: RAISR on Y and the cheap upscale of both chroma planes without leaving HBM
+        if (inCr->step != inCb->step || outCr->step != outCb->step) return RNLErrorBadParameter;
+        if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
+        int rc = raisr_hip_process_frame_device(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
+                                                inCr->pData, inCb->pData, inCr->step, outCr->pData, outCb->pData, outCr->step,
+                                                (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height, G.externalStream);
+        if (rc == RAISR_HIP_OK && !G.externalStream) rc = raisr_hip_synchronize(G.ctx);
+        return rc != RAISR_HIP_OK ? failed() : RNLErrorNone;
+    }
     if (K <= 1) {
         if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
         const int rc = raisr_hip_process_host(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
@@ -470,7 +487,8 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
 
 RNLERRORTYPE RNLSetOpenCLContext(void *context, void *deviceID, int platformIndex, int deviceIndex)
 {
-    (void)context; (void)deviceID; (void)platformIndex;
+    (void)deviceID; (void)platformIndex;
+    G.externalStream = context;                       // asm = HIPExternal: the caller's hipStream_t (or NULL)
     G.device = deviceIndex < 0 ? 0 : deviceIndex;     // HIP device ordinal (vf_raisr `device=` option)
     G.deviceChosen = true;
     return RNLErrorNone;

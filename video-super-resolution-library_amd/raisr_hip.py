@@ -27,7 +27,7 @@ RNLErrorInsufficientResources = ctypes.c_int(0x80001000 - (1 << 32)).value
 RNLErrorUndefined = ctypes.c_int(0x80001001 - (1 << 32)).value
 RNLErrorBadParameter = ctypes.c_int(0x80001002 - (1 << 32)).value
 Randomness, CountOfBitsChanged = 1, 2
-AVX2, AVX512, OpenCL, OpenCLExternal, AVX512_FP16, HIP = 1, 2, 3, 4, 5, 6
+AVX2, AVX512, OpenCL, OpenCLExternal, AVX512_FP16, HIP, HIPExternal = 1, 2, 3, 4, 5, 6, 7
 VideoRange, FullRange = 1, 2
 
 HASH_AVX2, HASH_AVX512, HASH_FP16 = 1, 2, 5
@@ -171,8 +171,9 @@ def RNLHandler_Init(model_path, ratio, bit_depth=8, range_type=VideoRange, threa
                                  passes, two_pass_mode)
 
 
-def RNLHandler_SetOpenCLContext(platform_index=0, device_index=0):
-    return lib().RNLHandler_SetOpenCLContext(None, None, platform_index, device_index)
+def RNLHandler_SetOpenCLContext(platform_index=0, device_index=0, stream=None):
+    """device selection hook; `stream` (a hipStream_t value) only matters for asm = HIPExternal"""
+    return lib().RNLHandler_SetOpenCLContext(stream, None, platform_index, device_index)
 
 
 def RNLHandler_Deinit():
