@@ -120,6 +120,16 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by)
     bx = (int)(t - (unsigned)by * gx);
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on
+// gfx950 the fence makes every wave wait for ALL its outstanding global loads and stores (s_waitcnt vmcnt(0)) -- which
+// turns a register prefetch of the next tile into a stall, and makes a persistent workgroup wait for the write
+// acknowledgement of its output stores at every tile.  The kernels below exchange nothing through global memory inside a
+// workgroup, so they wait for their LDS traffic only.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_resize: centre-aligned bilinear with replicate border in exact integer arithmetic.
 // dst(y,x): n = (2d+1)*S - D, den = 2D per axis (reduced by gcd on the host: Sx,Dx,Sy,Dy).
@@ -656,6 +666,37 @@ __global__ __launch_bounds__(256) void k_debug_hash(const float* __restrict__ ab
 //   angle       rr = (xx - ay)/(xx + ay), |d rr| <= 2((ay+E_ay) E_L + (xx+E_L) E_ay) / (xx + ay - E_L - E_ay)^2 + 4 u,
 //               |P'(rr)| < 1 for the cubic P  =>  |ang_raw - ang_raw*| <= d rr + 1.5e-6;  q = ang 24/pi: + 2e-5
 // ------------------------------------------------------------------------------------------------
+// Gradient tile element: (gx, gy) as two floats, or -- for 8-bit content, whose gradients (|g| <= 255) are exact in
+// binary16 -- packed as two halves in one dword: half the LDS of the tile, and the products gx^2, gx gy, gy^2 of the
+// separable tensor come straight out of v_fma_mix_f32 (both operands binary16, exact fp32 product).
+struct h2g { unsigned v; };
+__device__ __forceinline__ f2 grad_load(const f2* p) { return *p; }
+__device__ __forceinline__ f2 grad_load(const h2g* p)
+{
+    const unsigned v = p->v;
+    return (f2){(float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16))};
+}
+__device__ __forceinline__ void grad_store(f2* p, float gx, float gy) { *p = (f2){gx, gy}; }
+__device__ __forceinline__ void grad_store(h2g* p, float gx, float gy)
+{
+    p->v = (unsigned)__builtin_bit_cast(uint16_t, (_Float16)gx) | ((unsigned)__builtin_bit_cast(uint16_t, (_Float16)gy) << 16);
+}
+__device__ __forceinline__ void grad_products(const f2* p, float& pa, float& pb, float& pd)
+{
+    const f2 g = *p;
+    pa = g.x * g.x; pb = g.x * g.y; pd = g.y * g.y;
+}
+__device__ __forceinline__ void grad_products(const h2g* p, float& pa, float& pb, float& pd)
+{
+    const unsigned v = p->v;
+    const float nz = -0.0f;                               // x * y == fma(x, y, -0) bit for bit
+    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(pa) : "v"(v), "v"(nz));
+    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(pb) : "v"(v), "v"(nz));
+    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(pd) : "v"(v), "v"(nz));
+}
+template <typename T> struct GradOf { using type = f2; };
+template <> struct GradOf<uint8_t> { using type = h2g; };
+
 struct SepW {
     float us[11];                // separable weights, sqrt(NF) folded in: us[i] us[k] ~ wT[k][i]
     float es1, es2;              // 1.42 eps, 2e-7 + eps^2
@@ -746,11 +787,12 @@ __device__ __forceinline__ void flavour_hash(const PassParams& P, const uint2* s
 // The reference's arithmetic for ONE pixel (lane-private): window origin (prow, pcol) in the gradient tile.  Same
 // operations in the same order as hash_phase (column accumulators over the 11 patch rows, sumitup_ps_512 fold), then
 // the flavour logic of hash_phase's epilogue.
-__device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& gw, const f2* sG, const uint2* sTab,
+template <typename GT>
+__device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& gw, const GT* sG, const uint2* sTab,
                                                       int prow, int pcol, int c, unsigned& hA, unsigned& hB)
 {
     constexpr int GW_ = 74;
-    const f2* base = sG + prow * GW_ + pcol;
+    const GT* base = sG + prow * GW_ + pcol;
     f2 curAD = {0.f, 0.f}, holdAD = {0.f, 0.f}, t1AD = {0.f, 0.f};
     float curB = 0.f, holdB = 0.f, t1B = 0.f;
 #pragma unroll 1
@@ -762,7 +804,7 @@ __device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& g
         for (int i = 0; i < 11; i++) {
             const float wv = gw.wT[k][i];
             const f2 w2 = {wv, wv};
-            const f2 gg = base[i * GW_ + k];
+            const f2 gg = grad_load(base + i * GW_ + k);
             const f2 pq = gg * w2;
             AD = __builtin_elementwise_fma(pq, gg, AD);
             B = __builtin_fmaf(pq.x, gg.y, B);
@@ -798,15 +840,16 @@ __device__ __forceinline__ float fold11(float S, bool lane3)
     const float r = z + row_shl<0x102>(z);
     return r + row_shl<0x101>(r);
 }
-__device__ __forceinline__ void exact_tensor16(const f2* sG, const float (&wl)[11], int prow, int pcol, int l, float& a, float& b, float& d)
+template <typename GT>
+__device__ __forceinline__ void exact_tensor16(const GT* sG, const float (&wl)[11], int prow, int pcol, int l, float& a, float& b, float& d)
 {
     constexpr int GW_ = 74;
-    const f2* base = sG + prow * GW_ + pcol + min(l, 10);
+    const GT* base = sG + prow * GW_ + pcol + min(l, 10);
     f2 AD = {0.f, 0.f};
     float B = 0.f;
     f2 gg[11];
 #pragma unroll
-    for (int i = 0; i < 11; i++) gg[i] = base[i * GW_];
+    for (int i = 0; i < 11; i++) gg[i] = grad_load(base + i * GW_);
 #pragma unroll
     for (int i = 0; i < 11; i++) {
         const f2 w2 = {wl[i], wl[i]};
@@ -823,7 +866,8 @@ __device__ __forceinline__ void exact_tensor16(const f2* sG, const float (&wl)[1
 // Approximate structure tensor of the lane's 4 pixels (rows [4w, 4w+4) of the tile, column = lane): separable 11 + 11 taps
 // on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4),
 // results as float4 per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
-__device__ __forceinline__ void tensor_ac(const SepW& S, const f2* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4])
+template <typename GT>
+__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4])
 {
     constexpr int GW_ = 74;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -831,8 +875,8 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const f2* sG, float4* s
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 14; t++) {
-            const f2 g = sG[(4 * rg + t) * GW_ + x];
-            const float pa = g.x * g.x, pb = g.x * g.y, pd = g.y * g.y;
+            float pa, pb, pd;
+            grad_products(sG + (4 * rg + t) * GW_ + x, pa, pb, pd);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = t - r;
@@ -849,7 +893,7 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const f2* sG, float4* s
     };
     vpass(lane, w);
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 4; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
     // software-pipelined by hand (next column's three float4 in flight during this column's 12 FMAs) and fenced per
@@ -877,8 +921,8 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const f2* sG, float4* s
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
-template <int LW>
-__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const f2* sG, float4* sV,
+template <int LW, typename GT>
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const GT* sG, float4* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
                                               int c0, int r0, unsigned long long& tstamp)
 {
@@ -1175,7 +1219,8 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     constexpr int TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
     __shared__ float sL[LH * LW];
-    __shared__ f2 sG[GH * GW_];
+    using GT = typename GradOf<T>::type;
+    __shared__ GT sG[GH * GW_];
     __shared__ float4 sV[3 * 4 * GW_];
     __shared__ uint2 sTab[128];
     __shared__ uint8_t sH[TH * TW];
@@ -1198,7 +1243,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
             const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
-            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
         };
         const int wu = __builtin_amdgcn_readfirstlane(w);
         __builtin_assume(wu >= 0 && wu < 4);
@@ -1215,7 +1260,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     }
     __syncthreads();
     RAISR_STAMP(P, 1, tstamp);
-    if (PART != 2) hash_phase_ac<LW>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
+    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
     else {
         for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)((i * 7) % 216); sH2[i] = 0xFFu; }
         __syncthreads();
@@ -1271,13 +1316,14 @@ __device__ __forceinline__ void xcd_tile_of(unsigned t, unsigned gx, unsigned n,
 // Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the next tile's LR window
 // into registers while it computes the current one.
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, PassParams P, SepW S, FixLists F,
+__global__ __launch_bounds__(256, 5) void k_hash_ac(const T* __restrict__ lr, PassParams P, SepW S, FixLists F,
                                                     uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
 {
     constexpr int TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
     __shared__ float sL[LH * LW];             // 8624 B; after the gradient stage: worklist [1024 x u16]
-    __shared__ f2 sG[GH * GW_];
+    using GT = typename GradOf<T>::type;
+    __shared__ GT sG[GH * GW_];
     __shared__ float4 sV[3 * 4 * GW_];
     __shared__ unsigned sCnt[2];
     uint16_t* sList = reinterpret_cast<uint16_t*>(sL);
@@ -1298,7 +1344,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, Pa
         const unsigned tile_pos = ((unsigned)by << 16) | (unsigned)bx;
         if (threadIdx.x < 2) sCnt[threadIdx.x] = 0;
         store_tile<LH, 76, LW>(R, sL);
-        __syncthreads();
+        lds_barrier();
         if (t + gridDim.x < ntiles) {                       // next tile's window: in flight during this tile's arithmetic
             xcd_tile_of(t + gridDim.x, (unsigned)F.tiles_x, ntiles, bx, by);
             load_tile<LH, 76>(lr, P.lr_pitch, P.W, P.H, by * TH, bx * TW, R);
@@ -1307,7 +1353,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, Pa
             auto grad = [&](int ty, int tx) {
                 const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
                 const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
-                sG[ty * GW_ + tx] = (f2){gxv, gyv};
+                grad_store(&sG[ty * GW_ + tx], gxv, gyv);
             };
             const int wu = __builtin_amdgcn_readfirstlane(w);
             __builtin_assume(wu >= 0 && wu < 4);
@@ -1322,7 +1368,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, Pa
                 if (idx < NR) grad(ty, tx);
             }
         }
-        __syncthreads();
+        lds_barrier();
         float ta[4], tb[4], td[4];
         tensor_ac(S, sG, sV, ta, tb, td);
 
@@ -1353,7 +1399,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, Pa
             nUnc += (zone && !cert) ? 1u : 0u;
         }
         if (P.cert_stats && nUnc) atomicAdd(&sCnt[1], nUnc);
-        __syncthreads();
+        lds_barrier();
         const unsigned n = sCnt[0];
         if (n <= kSparseMax) {
             if (threadIdx.x < n) {
@@ -1370,7 +1416,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_ac(const T* __restrict__ lr, Pa
             if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
             atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
         }
-        __syncthreads();                                     // worklist (in the LR window's space) and counters are free again
+        lds_barrier();                                     // worklist (in the LR window's space) and counters are free again
     }
 }
 
@@ -1765,7 +1811,7 @@ __global__ __launch_bounds__(1024) void k_filter_lds16(const T* __restrict__ lr,
 
     int tile = wg;
     if (tile < ntiles) { fetch(tile); stash(0); }
-    __syncthreads();
+    lds_barrier();
     int cur = 0;
     const float negzero = -0.0f;
     for (; tile < ntiles; tile += nwg, cur ^= 1) {
@@ -1875,9 +1921,10 @@ __global__ __launch_bounds__(1024) void k_filter_lds16(const T* __restrict__ lr,
             if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
         }
         if (nxt < ntiles) stash(cur ^ 1);
-        __syncthreads();
+        lds_barrier();
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // k_blend (CountOfBitsChanged): CTCountOfBitsChangedSegment_AVX256_32f, Raisr_AVX256.cpp:68-166,
