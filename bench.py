@@ -55,7 +55,7 @@ CONFIGS = {
     "C4": (1280, 720, 1920, 1080, "filters_1.5x/filters_denoise", 8, 2, 2, 5, "720p->1080p 1.5x, filters_denoise, 2-pass mode 2, 8-bit, AVX512FP16-exact"),
     "C5": (3840, 2160, 7680, 4320, "filters_2x/filters_highres", 10, 1, 1, 2, "4K->8K 2x, filters_highres, 1-pass, 10-bit, AVX512-exact"),
 }
-DOMINANT = ("k_hashfilter_ac", "k_hashfilter", "k_hashfilter16", "k_filter_lds", "k_hash_ac", "k_hash", "k_hash16", "k_filter", "k_filter16")
+DOMINANT = ("k_hashfilter_ac", "k_hashfilter", "k_hashfilter16", "k_filter_lds16", "k_hash_ac", "k_hash", "k_hash16", "k_filter", "k_filter16")
 
 
 def parse():

@@ -1,17 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
-# Output goes to gpurun_out/prof_<tag>/ ; summarise afterwards with scripts/summarize_profiles.py.
+# usage: scripts/profile_gpu.sh <tag> [ENV=VAL ...]     e.g.  scripts/profile_gpu.sh r02   |   scripts/profile_gpu.sh r02_split RAISR_HIP_SPLIT=1
+# Output goes to gpurun_out/prof_<tag>/ ; summarise afterwards (in the build container, same sources) with scripts/summarize_profiles.py <tag>.
 # PMC passes are separate runs with --kernel-trace only (gpurun refuses pmc + sys-trace combos).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+echo "$*" > "$OUT/variant.txt"
+for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 20 --warmup 3 > "$OUT/stats.log" 2>&1
-$B --steps 20 --warmup 3 > "$OUT/bench_events.json" 2> "$OUT/bench_events.err"
-PMC="$B --steps 2 --warmup 1 --lanes 1 --no-kernel-timing"
+B="python $ROOT/bench.py --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 3 --warmup 1 > "$OUT/stats.log" 2>&1
+$B --steps 3 --warmup 1 > "$OUT/bench_events.json" 2> "$OUT/bench_events.err"
+PMC="$B --steps 2 --warmup 1 --lanes 1 --no-kernel-timing --frames-per-step 8"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS -d "$OUT/pmc_sq" -- $PMC > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d "$OUT/pmc_lds" -- $PMC > "$OUT/pmc_lds.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $PMC > "$OUT/pmc_fetch.log" 2>&1

@@ -13,17 +13,17 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERN = ("k_hashfilter16", "k_hashfilter", "k_hash16", "k_filter16", "k_blend16", "k_hash", "k_filter", "k_blend", "k_resize2x", "k_resize")
+import re
 
 
 def short(name):
-    for k in KERN:
-        if k + "<" in name or k + "(" in name or name.endswith(k):
-            return k
-    return name[:60]
+    m = re.search(r"\bk_\w+", name)
+    return m.group(0) if m else name[:60]
 
 
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --steps 20 --warmup 3` (1080p->4K 2x, highres, 1-pass, 4 lanes x 24 frames/step)", ""]
+variant = open(os.path.join(src, "variant.txt")).read().strip() if os.path.exists(os.path.join(src, "variant.txt")) else ""
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1` (C2: 1080p->4K 2x, highres, 1-pass, 4 lanes x 768 frames/step)"
+         + (f", environment: `{variant}`" if variant else ""), ""]
 f = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # newest run first
 if f:
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
@@ -90,8 +90,15 @@ if pmc:
             traffic[k] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if traffic:
         lines += ["## HBM-side bytes per launch (2 * FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
-        dom = "k_hashfilter" if "k_hashfilter" in traffic else "k_hash"
-        json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel": traffic,
+        dom = next((k for k in ("k_hashfilter_ac", "k_hashfilter", "k_filter_lds16", "k_hash") if k in traffic), None)
+        import hashlib
+        hs = hashlib.sha256()
+        cs = os.path.join(root, "video-super-resolution-library_amd", "csrc")
+        for fn in sorted(os.listdir(cs)):                      # same digest as bench.py source_hash(): the figure is only quoted for these sources
+            if fn.endswith((".hip", ".h", ".cpp")):
+                hs.update(fn.encode()); hs.update(open(os.path.join(cs, fn), "rb").read())
+        json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic,
+                   "source_sha256": hs.hexdigest(), "variant": variant,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--lanes 1); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                              "gfx950 FETCH_SIZE half-count confirmed on k_blend's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
                   open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)

@@ -442,14 +442,27 @@ __device__ __attribute__((noinline)) int hash_px_legacy(float a, float b, float 
 // ------------------------------------------------------------------------------------------------
 __constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
 
+// Gradient tile element (gx, gy).  (A binary16-packed tile -- 8-bit gradients are exact in binary16 and v_fma_mix_f32 gives
+// the products directly -- halves the tile's LDS, but measured 3 % slower in k_hashfilter_ac and no faster in k_hash_ac.)
+__device__ __forceinline__ f2 grad_load(const f2* p) { return *p; }
+__device__ __forceinline__ void grad_store(f2* p, float gx, float gy) { *p = (f2){gx, gy}; }
+__device__ __forceinline__ void grad_products(const f2* p, float& pa, float& pb, float& pd)
+{
+    const f2 g = *p;
+    pa = g.x * g.x; pb = g.x * g.y; pd = g.y * g.y;
+}
+template <typename T> struct GradOf { using type = f2; };
+
+
+
 // AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
 // LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
 //
 // hash_phase: the work of one tile once its LR window (origin (r0-6, c0-6), row stride LW) is in sL.  Returns, per
 // lane (= column c0+lane) and row j of the wave's R rows, hA = first hash (0xFF: pixel not filtered) and hB = the
 // AVX2 re-hash of an overlap column (0xFF elsewhere).  Ends with every wave past its last LDS read of sG.
-template <int R, bool AVX2ALL, int LW>
-__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, f2* sG,
+template <int R, bool AVX2ALL, int LW, typename GT = f2>
+__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, GT* sG,
                                            const uint2* sTab, const uint16_t* sLut, int c0, int r0,
                                            unsigned (&hA)[R], unsigned (&hB)[R])
 {
@@ -461,7 +474,7 @@ __device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
             const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
-            sG[ty * GW_ + tx] = (f2){gxv, gyv};
+            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
         };
         const int wu = __builtin_amdgcn_readfirstlane(w);
         __builtin_assume(wu >= 0 && wu < 4);
@@ -490,7 +503,7 @@ __device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw
         const int k = c_col_order[kk];
         f2 g[R + 10];
 #pragma unroll
-        for (int t = 0; t < R + 10; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
+        for (int t = 0; t < R + 10; t++) g[t] = grad_load(&sG[(w * R + t) * GW_ + lane + k]);
         f2 AD[R];
         float B[R];
 #pragma unroll
@@ -666,37 +679,6 @@ __global__ __launch_bounds__(256) void k_debug_hash(const float* __restrict__ ab
 //   angle       rr = (xx - ay)/(xx + ay), |d rr| <= 2((ay+E_ay) E_L + (xx+E_L) E_ay) / (xx + ay - E_L - E_ay)^2 + 4 u,
 //               |P'(rr)| < 1 for the cubic P  =>  |ang_raw - ang_raw*| <= d rr + 1.5e-6;  q = ang 24/pi: + 2e-5
 // ------------------------------------------------------------------------------------------------
-// Gradient tile element: (gx, gy) as two floats, or -- for 8-bit content, whose gradients (|g| <= 255) are exact in
-// binary16 -- packed as two halves in one dword: half the LDS of the tile, and the products gx^2, gx gy, gy^2 of the
-// separable tensor come straight out of v_fma_mix_f32 (both operands binary16, exact fp32 product).
-struct h2g { unsigned v; };
-__device__ __forceinline__ f2 grad_load(const f2* p) { return *p; }
-__device__ __forceinline__ f2 grad_load(const h2g* p)
-{
-    const unsigned v = p->v;
-    return (f2){(float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16))};
-}
-__device__ __forceinline__ void grad_store(f2* p, float gx, float gy) { *p = (f2){gx, gy}; }
-__device__ __forceinline__ void grad_store(h2g* p, float gx, float gy)
-{
-    p->v = (unsigned)__builtin_bit_cast(uint16_t, (_Float16)gx) | ((unsigned)__builtin_bit_cast(uint16_t, (_Float16)gy) << 16);
-}
-__device__ __forceinline__ void grad_products(const f2* p, float& pa, float& pb, float& pd)
-{
-    const f2 g = *p;
-    pa = g.x * g.x; pb = g.x * g.y; pd = g.y * g.y;
-}
-__device__ __forceinline__ void grad_products(const h2g* p, float& pa, float& pb, float& pd)
-{
-    const unsigned v = p->v;
-    const float nz = -0.0f;                               // x * y == fma(x, y, -0) bit for bit
-    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(pa) : "v"(v), "v"(nz));
-    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(pb) : "v"(v), "v"(nz));
-    asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(pd) : "v"(v), "v"(nz));
-}
-template <typename T> struct GradOf { using type = f2; };
-template <> struct GradOf<uint8_t> { using type = h2g; };
-
 struct SepW {
     float us[11];                // separable weights, sqrt(NF) folded in: us[i] us[k] ~ wT[k][i]
     float es1, es2;              // 1.42 eps, 2e-7 + eps^2
@@ -784,42 +766,6 @@ __device__ __forceinline__ void flavour_hash(const PassParams& P, const uint2* s
     hA = (inA || inB) ? h : 0xFFu;
 }
 
-// The reference's arithmetic for ONE pixel (lane-private): window origin (prow, pcol) in the gradient tile.  Same
-// operations in the same order as hash_phase (column accumulators over the 11 patch rows, sumitup_ps_512 fold), then
-// the flavour logic of hash_phase's epilogue.
-template <typename GT>
-__device__ __forceinline__ void exact_pixel(const PassParams& P, const GaussW& gw, const GT* sG, const uint2* sTab,
-                                                      int prow, int pcol, int c, unsigned& hA, unsigned& hB)
-{
-    constexpr int GW_ = 74;
-    const GT* base = sG + prow * GW_ + pcol;
-    f2 curAD = {0.f, 0.f}, holdAD = {0.f, 0.f}, t1AD = {0.f, 0.f};
-    float curB = 0.f, holdB = 0.f, t1B = 0.f;
-#pragma unroll 1
-    for (int kk = 0; kk < 11; kk++) {
-        const int k = c_col_order[kk];
-        f2 AD = {0.f, 0.f};
-        float B = 0.f;
-#pragma unroll
-        for (int i = 0; i < 11; i++) {
-            const float wv = gw.wT[k][i];
-            const f2 w2 = {wv, wv};
-            const f2 gg = grad_load(base + i * GW_ + k);
-            const f2 pq = gg * w2;
-            AD = __builtin_elementwise_fma(pq, gg, AD);
-            B = __builtin_fmaf(pq.x, gg.y, B);
-        }
-        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
-        if (start) { curAD = AD; curB = B; }
-        else { curAD = curAD + AD; curB = curB + B; }
-        if (kk == 2 || kk == 8) { holdAD = curAD; holdB = curB; }
-        if (kk == 5) { t1AD = holdAD + curAD; t1B = holdB + curB; }
-    }
-    const f2 ad = (holdAD + curAD) + t1AD;
-    const float bb = (holdB + curB) + t1B;
-    flavour_hash(P, sTab, ad.x, bb, ad.y, c, hA, hB);
-}
-
 // Exact tensor of up to four worklist pixels per wave with 16 lanes per pixel: lane l < 11 of a group runs the
 // reference's chain of patch column l (the 11 patch rows in order, weights wl[i] = wT[l][i]); the 11 column sums are
 // folded in sumitup_ps_512's association with DPP row shifts (row_shl:n -- lane i reads lane i+n of its row of 16):
@@ -893,7 +839,7 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* s
     };
     vpass(lane, w);
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
-    lds_barrier();
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
     // software-pipelined by hand (next column's three float4 in flight during this column's 12 FMAs) and fenced per
@@ -921,8 +867,9 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* s
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
+constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilter_ac: more uncertain pixels -> the whole tile takes the exact routine
 template <int LW, typename GT>
-__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const GT* sG, float4* sV,
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, float4* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
                                               int c0, int r0, unsigned long long& tstamp)
 {
@@ -938,7 +885,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     const int fl = inB ? 1 : 0;                            // the AVX2 flavour's wider table error covers the re-hashed columns too
     const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
     const int ai_bzero = P.ai_bzero;                    // angle bucket of b == 0 (xx = 1, ay = 1e-10), evaluated on the host
-    unsigned nUnc = 0;
+    unsigned nUnc = 0, certbits = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int prow = 4 * w + j;
@@ -956,9 +903,10 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         const bool unc = zone && (!cert || P.cert_check);
         sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
         sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
+        certbits |= (cert ? 1u : 0u) << j;
         if (unc) {
             const unsigned slot = atomicAdd(sCnt, 1u);
-            sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
+            if (slot < kListMax) sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
         }
         nUnc += (zone && !cert) ? 1u : 0u;
     }
@@ -972,7 +920,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
     unsigned bad = 0;
-    if (n <= 48u) {
+    if (n <= kListMax) {
         // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
         if (n) {
             const int g = lane >> 4, l = lane & 15;
@@ -995,18 +943,17 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
             }
         }
     } else {
-        // long list (synthetic content, self-check mode): one lane per pixel, 64 pixels per wave and round
-        for (unsigned base = 64u * w; base < n; base += 256u) {
-            const unsigned e = base + lane;
-            if (e < n) {
-                const unsigned ent = sList[e];
-                const int prow = (ent >> 6) & 15, pcol = ent & 63;
-                unsigned hA, hB;
-                exact_pixel(P, gw, sG, sTab, prow, pcol, c0 + pcol, hA, hB);
-                if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
-                sH[prow * TW + pcol] = (uint8_t)hA;
-                sH2[prow * TW + pcol] = (uint8_t)hB;
-            }
+        // long list (synthetic content, self-check mode): the whole tile through the all-exact routine (hash_phase; it
+        // rebuilds the gradient tile from the LR window), every wave busy.  The AVX2 flavour takes its out-of-line path.
+        unsigned hA[4], hB[4];
+        hash_phase<4, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int prow = 4 * w + j;
+            if (hA[j] != 0xFFu && ((certbits >> j) & 1u) &&
+                (sH[prow * TW + lane] != (uint8_t)hA[j] || (hB[j] != 0xFFu && sH2[prow * TW + lane] != (uint8_t)hB[j]))) bad++;
+            sH[prow * TW + lane] = (uint8_t)hA[j];
+            sH2[prow * TW + lane] = (uint8_t)hB[j];
         }
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
@@ -1225,7 +1172,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     __shared__ uint2 sTab[128];
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];
-    __shared__ uint16_t sList[1024];          // worklist entries
+    __shared__ uint16_t sList[kListMax];      // worklist entries
     __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1260,7 +1207,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     }
     __syncthreads();
     RAISR_STAMP(P, 1, tstamp);
-    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
+    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
     else {
         for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)((i * 7) % 216); sH2[i] = 0xFFu; }
         __syncthreads();
@@ -1525,174 +1472,15 @@ __global__ __launch_bounds__(256, 4) void k_fix_dense(const T* __restrict__ lr, 
 
 
 // ------------------------------------------------------------------------------------------------
-// k_filter_lds: the filter stage with the filter bank in LDS (north_star: "per-CU LDS cache").
+// k_filter_lds16: the filter stage with the filter bank in LDS (north_star: "per-CU LDS cache"), split pipeline only.
 // The stand-alone k_filter is bound by the vector L1: 512 B of coefficients per pixel at 64 B/clk/CU.  One pixel
 // type's bank is 216 x 128 floats = 108 KB and fits the 160 KB LDS, where a lane fetches its 8 coefficients with two
 // ds_read_b128 (256 B/clk/CU).  So: persistent workgroups of 16 waves, one per CU, each owning ONE pixel type
 // (blockIdx & 3): it loads that type's bank once per launch and walks the tiles of its type -- 64 x 16 pixels of the
 // type = a 128 x 32 pixel region of the plane (SP = 2; ratio 1.5 has a single type and SP = 1) -- with the LR window of
 // the next tile (and its buckets) prefetched into registers while the current one is filtered.  Wave q of the workgroup
-// filters row q of the tile with the arithmetic of filter_phase (16 lanes per pixel, DPP tree, accept test).
-// LDS: bank 217 rows (row 216 = zeros: "not filtered") 111 104 B + 2 x LR window + 2 x bucket tiles.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int SP>
-__global__ __launch_bounds__(1024) void k_filter_lds(const T* __restrict__ lr, const uint8_t* __restrict__ hash, PassParams P,
-                                                     float* __restrict__ hr, unsigned* __restrict__ fix_counters)
-{
-    constexpr int TW = 64, TH = 16;                                  // pixels of the type per tile
-    constexpr int WW = SP * (TW - 1) + 11, WH = SP * (TH - 1) + 11;  // LR window of a tile: 137 x 41 (SP = 2), 74 x 26 (SP = 1)
-    constexpr int LW = SP == 2 ? 141 : 77;                           // row stride = 13 mod 32: a lane group's taps of two patch rows hit different banks
-    constexpr int NLOAD = (WW * WH + 1023) / 1024;
-    extern __shared__ float smem[];
-    float* sBank = smem;                                             // [217][2][16][4]
-    float* sT0 = sBank + 217 * 128;
-    float* sT1 = sT0 + WH * LW;
-    uint8_t* sHb = reinterpret_cast<uint8_t*>(sT1 + WH * LW);        // [2][2][TH * TW]: buffer, {first, second hash}
-
-    if (fix_counters && blockIdx.x == 0 && threadIdx.x == 0) fix_counters[0] = 0;   // follows the fix kernels in stream order
-    const int ntypes = SP * SP;
-    const int type = (int)(blockIdx.x % (unsigned)ntypes);
-    const int tr = type >> 1, tc = type & 1;
-    // first row / column of the filtered zone with this parity: t = ((r-5)&1)*2 + ((c-5)&1) (Raisr.cpp:1093)
-    const int rbase = SP == 2 ? kMargin + (tr ^ 1) : kMargin;
-    const int cbase = SP == 2 ? kMargin + (tc ^ 1) : kMargin;
-    const int ncols = (P.c_final - cbase + SP - 1) / SP, nrows = (P.H - kMargin - rbase + SP - 1) / SP;   // pixels of the type
-    const int tiles_x = (ncols + TW - 1) / TW, tiles_y = (nrows + TH - 1) / TH;
-    const int ntiles = (ncols > 0 && nrows > 0) ? tiles_x * tiles_y : 0;
-    const int wg = (int)(blockIdx.x / (unsigned)ntypes), nwg = (int)(gridDim.x / (unsigned)ntypes);
-
-    // ---- the type's bank: HBM [hash][type][128] -> LDS [hash][half][lane][4] (lane l's chunks 4 half .. 4 half + 3) ----
-    for (int e = (int)threadIdx.x; e < 217 * 128; e += 1024) {
-        const int h = e >> 7, k = e & 127, ch = k >> 4, l = k & 15;
-        const float v = h < 216 ? P.bank[((size_t)h * ntypes + type) * kTapsPad + k] : 0.0f;
-        sBank[h * 128 + (ch >> 2) * 64 + l * 4 + (ch & 3)] = v;
-    }
-
-    const int lane = threadIdx.x & 63, q = (int)(threadIdx.x >> 6);  // wave q <-> tile row q
-    const int g = lane >> 4, l = lane & 15;
-    int off[8];
-#pragma unroll
-    for (int ch = 0; ch < 8; ch++) {
-        const int k = 16 * ch + l;
-        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;        // padding taps: coefficient is +0, any finite pixel will do
-    }
-
-    T regs[NLOAD];
-    unsigned rh = 0xFFu, rh2 = 0xFFu;
-    auto fetch = [&](int tile) {                                      // global -> registers: LR window and buckets of a tile
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const int X0 = cbase + SP * TW * tx - 5, Y0 = rbase + SP * TH * ty - 5;
-#pragma unroll
-        for (int it = 0; it < NLOAD; it++) {
-            const int e = min((int)threadIdx.x + 1024 * it, WW * WH - 1);
-            const int wy = e / WW, wx = e - wy * WW;
-            const int gy = min(max(Y0 + wy, 0), P.H - 1), gx = min(max(X0 + wx, 0), P.W - 1);
-            regs[it] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gx];
-        }
-        const int r = rbase + SP * (TH * ty + q), c = cbase + SP * (TW * tx + lane);
-        const bool in = r < P.H - kMargin && c < P.c_final;
-        rh = in ? hash[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] : 0xFFu;
-        rh2 = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : 0xFFu;
-    };
-    auto stash = [&](int buf) {                                       // registers -> LDS buffer `buf`
-        float* sT = buf ? sT1 : sT0;
-#pragma unroll
-        for (int it = 0; it < NLOAD; it++) {
-            const int e = (int)threadIdx.x + 1024 * it;
-            const int wy = e / WW, wx = e - wy * WW;
-            if (e < WW * WH) sT[wy * LW + wx] = (float)regs[it];
-        }
-        sHb[(buf * 2 + 0) * TH * TW + q * TW + lane] = (uint8_t)rh;
-        sHb[(buf * 2 + 1) * TH * TW + q * TW + lane] = (uint8_t)rh2;
-    };
-
-    int tile = wg;
-    if (tile < ntiles) { fetch(tile); stash(0); }
-    __syncthreads();
-    int cur = 0;
-    for (; tile < ntiles; tile += nwg, cur ^= 1) {
-        const int nxt = tile + nwg;
-        if (nxt < ntiles) fetch(nxt);                                 // in flight during this tile's arithmetic
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const float* sT = cur ? sT1 : sT0;
-        const uint8_t* sH = sHb + (cur * 2 + 0) * TH * TW + q * TW;
-        const uint8_t* sH2 = sHb + (cur * 2 + 1) * TH * TW + q * TW;
-        const int r = rbase + SP * (TH * ty + q);
-        {
-            // window row of image row r - 5 is SP q; pixel m of the row sits at window column SP m + 5
-            const float* rowbase = sT + (SP * q) * LW + SP * g;
-            const char* tap[8];
-#pragma unroll
-            for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(rowbase + off[ch]);
-            const char* ctr = reinterpret_cast<const char*>(rowbase + 5 * LW + 5);
-#define RAISR_T_F(p, s) (*reinterpret_cast<const float*>((p) + (16 * SP) * (s)))
-            float keep = 0.0f;
-            const bool anyB = sH2[lane] != 0xFFu;
-            const char* ctrq = ctr + (64 * SP) * (l >> 2);           // centre pixel of the step this lane's quad ends up with
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float part[4];
-#pragma unroll
-                for (int mm = 0; mm < 4; mm++) {
-                    const int st = j + 4 * mm;
-                    const unsigned hA = min((unsigned)sH[4 * st + g], 216u);      // 0xFF (not filtered) -> the zero row
-                    const float4 fa = *reinterpret_cast<const float4*>(sBank + hA * 128u + (unsigned)l * 4u);
-                    const float4 fb = *reinterpret_cast<const float4*>(sBank + hA * 128u + 64u + (unsigned)l * 4u);
-                    float acc = RAISR_T_F(tap[0], st) * fa.x;
-                    acc = __builtin_fmaf(RAISR_T_F(tap[1], st), fa.y, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[2], st), fa.z, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[3], st), fa.w, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[4], st), fb.x, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[5], st), fb.y, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[6], st), fb.z, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[7], st), fb.w, acc);
-                    acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
-                    part[mm] = acc + row_ror<0x124>(acc);          // r4[i] = r8[i] + r8[i+4]
-                }
-                float v = part[0];
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[3]), "s"(0xf000f000f000f000ull));
-                v = v + quad_perm<0x4e>(v);
-                v = v + quad_perm<0xb1>(v);
-                float res = RAISR_T_F(ctrq, j);
-                if (v > P.lo && v < P.hi) res = v;
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
-            }
-            if (__any(anyB)) {                                       // tail columns: AVX2 re-hash (keep-first-if-rejected)
-#pragma unroll 1
-                for (int st = 0; st < 16; st++) {
-                    const unsigned hB = sH2[4 * st + g];
-                    if (hB == 0xFFu) continue;
-                    const float4 fa = *reinterpret_cast<const float4*>(sBank + hB * 128u + (unsigned)l * 4u);
-                    const float4 fb = *reinterpret_cast<const float4*>(sBank + hB * 128u + 64u + (unsigned)l * 4u);
-                    float acc = RAISR_T_F(tap[0], st) * fa.x;
-                    acc = __builtin_fmaf(RAISR_T_F(tap[1], st), fa.y, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[2], st), fa.z, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[3], st), fa.w, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[4], st), fb.x, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[5], st), fb.y, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[6], st), fb.z, acc);
-                    acc = __builtin_fmaf(RAISR_T_F(tap[7], st), fb.w, acc);
-                    const float v = tree16(acc);
-                    if (st == l) {
-                        if (v > P.lo && v < P.hi) keep = v;
-                        else if (P.randomness) keep = RAISR_T_F(ctr, st);
-                    }
-                }
-            }
-#undef RAISR_T_F
-            const int c = cbase + SP * (TW * tx + 4 * l + g);
-            if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
-        }
-        if (nxt < ntiles) stash(cur ^ 1);
-        __syncthreads();
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// k_filter_lds16: k_filter_lds with the LR window held as binary16 and TWO pixels per lane and step.
+// filters row q of the tile.  LDS: bank 217 rows (row 216 = zeros: "not filtered") 111 104 B + 2 x LR window + 2 x bucket tiles.
+// The LR window is held as binary16 with TWO pixels per lane and step:
 // 8- and 10-bit samples are exact in binary16, and v_fma_mix_f32 multiplies a binary16 operand (either half of a
 // VGPR) into an fp32 FMA -- bit for bit the fp32 FMA of the converted value.  The window is stored de-interleaved by
 // column parity (pixels of one type are SP columns apart, so the two pixels a lane works on are neighbours in their
@@ -2201,8 +1989,7 @@ struct raisr_hip_ctx {
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
-    bool lds16 = true;                         // binary16 LR window + two pixels per lane (8/10-bit content); RAISR_HIP_LDS16=0: fp32 window
-    int n_cus = 256;                           // persistent k_filter_lds grid: one workgroup per CU (multiple of 4)
+    int n_cus = 256;                           // persistent k_filter_lds16 grid: one workgroup per CU (multiple of 4)
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
     FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
     size_t fix_tiles = 0;
@@ -2354,22 +2141,14 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             else
                 hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
-            if (c->lds_filter) {
+            if (c->lds_filter && c->cfg.bits <= 10) {             // samples above 10 bits are not exact in binary16: k_filter
                 const bool sp2 = P.pixel_types == 4;
-                const int wh = sp2 ? 41 : 26, lw = sp2 ? 141 : 77;
-                const size_t shmem = (size_t)217 * 128 * 4 + 2 * (size_t)wh * lw * 4 + 4 * 1024;
-                if (c->cfg.bits <= 10 && c->lds16) {
-                    const size_t sh16 = (size_t)217 * 128 * 4 + 2 * (size_t)wh * (sp2 ? 286 : 154) * 2 + 4 * 1024;
-                    timer_begin(c, "k_filter_lds16", s, slot);
-                    if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
-                    else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
-                    timer_end(c, s, slot);
-                } else {
-                timer_begin(c, "k_filter_lds", s, slot);
-                if (sp2) hipLaunchKernelGGL((k_filter_lds<TOut, 2>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
-                else hipLaunchKernelGGL((k_filter_lds<TOut, 1>), dim3(c->n_cus), dim3(1024), shmem, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                const int wh = sp2 ? 41 : 26;
+                const size_t sh16 = (size_t)217 * 128 * 4 + 2 * (size_t)wh * (sp2 ? 286 : 154) * 2 + 4 * 1024;
+                timer_begin(c, "k_filter_lds16", s, slot);
+                if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
-                }
             } else {
                 timer_begin(c, "k_filter", s, slot);
                 hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
@@ -2570,15 +2349,10 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
-    if (const char* e = getenv("RAISR_HIP_LDS16")) c->lds16 = atoi(e) != 0;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 4) c->n_cus = prop.multiProcessorCount & ~3;
-        // k_filter_lds declares ~160 KB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        // k_filter_lds16 declares ~160 KB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
