@@ -142,7 +142,6 @@ def certify(a, b, d, P, eps, E14):
         ci = (qc[0] <= coh).astype(np.int32) + (qc[1] <= coh)
         # angle
         E_b = f(0.5 * eps) * T
-        bzero = (a == 0) | (d == 0)                                  # all gx or all gy of the window are 0: b == 0 exactly
         bsure = np.abs(b) > E_b
         ay = np.abs(b) + f(1e-10)
         xx = np.where(m >= 0, m + s, b * b / (s - m))               # (s - m)(s + m) = b^2
@@ -162,12 +161,9 @@ def certify(a, b, d, P, eps, E14):
         fr = q - k
         c_ang = okx & bsure & (np.abs(ang_raw) > dang) & ((k < 1) | (fr > dq)) & ((k > 22) | (f(1) - fr > dq))
         ai = k.astype(np.int32)
-        # b == 0 exactly: xx = 1, constant angle -> 23
-        c_ang = np.where(bzero, True, c_ang)
-        ai = np.where(bzero, 23, ai)
         cert = ok & c_str & c_coh & c_ang
-        certify.parts = dict(ok=ok, c_str=c_str, okc=okc, c_coh=c_coh, okx=okx, bsure=bsure | bzero, c_ang=c_ang,
-                             angraw=(np.abs(ang_raw) > dang) | bzero)
+        certify.parts = dict(ok=ok, c_str=c_str, okc=okc, c_coh=c_coh, okx=okx, bsure=bsure, c_ang=c_ang,
+                             angraw=(np.abs(ang_raw) > dang))
         zero = (T == 0)                                              # flat window: X == X' == 0 exactly -> bucket of (0,0,0)
         bucket = ai * 9 + si * 3 + ci
     return bucket, cert, zero

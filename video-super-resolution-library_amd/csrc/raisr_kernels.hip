@@ -89,7 +89,6 @@ struct PassParams {
     int write_hash;              // fused kernel: also write the hash plane (introspection for tests)
     unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels} or null
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
-    int ai_bzero;                // angle bucket the reference's hash gives when b == 0 (xx = 1): a constant of the model's qangle
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
     unsigned long long* prof;    // profiling aid: shader-clock cycles per phase of the certified hash stage, summed over tiles (or null)
@@ -689,7 +688,7 @@ struct SepW {
 struct HashQf { float qangle, qs0, qs1, qc0, qc1; };
 
 // returns true when the bucket is certified
-__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, int ai_bzero, unsigned& bucket)
+__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, unsigned& bucket)
 {
     const float U1 = 5.9604645e-8f;                      // 2^-24
     const float pi = 3.141592653f;
@@ -740,10 +739,8 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     const float fr = q - k;
     const bool c_ang = (xx > 2.0f * E_L) & (D > 0.0f) & (ab > E_b) & (__builtin_fabsf(ang_raw) > dang) &
                        ((k < 1.0f) | (fr > dq)) & ((k > 22.0f) | (1.0f - fr > dq));
-    const bool bzero = (a == 0.0f) | (d == 0.0f);        // all gx (or all gy) of the window are 0: the reference's b is exactly 0
-    ok &= bzero | c_ang;
-    const int ai = bzero ? ai_bzero : (int)k;
-    bucket = (unsigned)(ai * 9 + si * 3 + ci);
+    ok &= c_ang;                                         // (a window without any gx or gy has L2 = 0 and is never certified)
+    bucket = (unsigned)((int)k * 9 + si * 3 + ci);
     return ok;
 }
 
@@ -884,7 +881,6 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
     const int fl = inB ? 1 : 0;                            // the AVX2 flavour's wider table error covers the re-hashed columns too
     const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
-    const int ai_bzero = P.ai_bzero;                    // angle bucket of b == 0 (xx = 1, ay = 1e-10), evaluated on the host
     unsigned nUnc = 0, certbits = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -892,7 +888,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         const int r = r0 + prow;
         const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
         unsigned bucket;
-        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, ai_bzero, bucket);
+        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket);
         const bool zero = (ta[j] + td[j]) == 0.0f;          // flat window: the reference's tensor is exactly (0, 0, 0) as well
         cert |= zero;
         // first hash: AVX-512 flavour where the column has one, else the AVX2 flavour; second hash: AVX2 flavour of the
@@ -1329,7 +1325,7 @@ __global__ __launch_bounds__(256, 5) void k_hash_ac(const T* __restrict__ lr, Pa
             const int r = r0 + prow;
             const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
             unsigned bucket;
-            bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, P.ai_bzero, bucket);
+            bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket);
             const bool zero = (ta[j] + td[j]) == 0.0f;
             cert |= zero;
             const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
@@ -2094,16 +2090,6 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
     P.gauss_dev = c->d_gauss;
     P.prof = c->d_prof;
-    {   // b == 0 in the reference's hash (Raisr_AVX512.cpp:151-173,204-233): xx = 1, ay = |0| + 1e-10, same fp32 operations
-        volatile float one = 1.0f, tiny = 1e-10f;
-        const float x1 = one, ay = 0.0f + tiny;
-        const float rr = (x1 - ay) / (x1 + ay);
-        float ang = fmaf(fmaf(0.1963f * rr, rr, -0.9817f), rr, (float)(3.14159265358979323846 / 4.0));
-        ang = ang + ((ang < 0.0f) ? 3.141592653f : 0.0f);
-        const float fl = floorf(ang * P.qangle);
-        const int ai = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
-        P.ai_bzero = ai < 0 ? 0 : (ai > 23 ? 23 : ai);
-    }
     return P;
 }
 
