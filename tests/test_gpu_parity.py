@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from common import CASES, folder, dtype_for
+from common import CASES, folder, dtype_for, oracle_y
 
 pytestmark = pytest.mark.gpu
 
@@ -132,3 +132,28 @@ def test_device_planes_with_row_pitch():
         out = dst.cpu().numpy()
         ref = _oracle(y, ("x", "filters_2x/filters_highres", (2, 1), bits, 1, 1, 2, False))
         assert np.array_equal(out[:, :2 * w], ref) and np.all(out[:, 2 * w:] == 7)
+
+
+@pytest.mark.parametrize("passes,mode,full", [(1, 1, False), (2, 1, True), (2, 2, False)])
+def test_fp16_pipeline_on_10bit_content(passes, mode, full):
+    """asm = avx512fp16 with 10-bit content: the reference runs its binary16 path there as well (Convert_8u16f_10bit, NF_10;
+    Raisr.cpp:978-982, Raisr_AVX512FP16.cpp:146-151) -- accumulators overflow binary16 on strong gradients, deterministically.
+    HIP binary16 pipeline vs the software-binary16 oracle, bit for bit."""
+    import raisr_hip as R
+    import synth
+    w, h = 152, 94
+    fold = "filters_2x/filters_denoise" if mode == 2 else "filters_2x/filters_highres"
+    case = ("x", fold, (2, 1), 10, passes, mode, 5, full)
+    for nm, y in (("natural", synth.natural_y(w, h, 10, seed=31)), ("random", synth.random_y(w, h, 10, seed=32)),
+                  ("checker", synth.checker_y(w, h, 10))):
+        ref = oracle_y(y, case)
+        dev = R.RaisrDevice(0)
+        try:
+            dev.set_model_from_folder(folder(fold), 10, passes)
+            dev.configure(w, h, 2 * w, 2 * h, bits=10, full_range=full, passes=passes, mode=mode, hash_variant=R.HASH_FP16)
+            out = np.zeros((2 * h, 2 * w), np.uint16)
+            dev.process_host(y, out)
+        finally:
+            dev.close()
+        bad = np.argwhere(out != ref)
+        assert bad.size == 0, (nm, len(bad), bad[:5].tolist())

@@ -278,11 +278,11 @@ RNLERRORTYPE RNLInit(std::string &modelPath, float ratio, unsigned int bitDepth,
         std::cout << "ASM Type: OpenCL requested, but OpenCL is not enabled.\n";
         return RNLErrorBadParameter;
     case AVX512_FP16:
-        if (bitDepth == 8) {
+        if (bitDepth <= 10) {   // 10-bit: the reference runs its binary16 path too (Convert_8u16f_10bit, NF_10), overflows and all
             G.hashVariant = RAISR_HIP_HASH_FP16;
             std::cout << "ASM Type: HIP gfx950 (AVX512FP16-exact numerics)\n";
-        } else {    // the binary16 pipeline overflows above 8-bit content (1023^2 > 65504)
-            std::cout << "ASM Type: AVX512FP16 numerics requested, but they are defined for 8-bit content only.  Changing to AVX512\n";
+        } else {    // 16-bit samples are not exact in binary16
+            std::cout << "ASM Type: AVX512FP16 numerics requested, but 16-bit samples are not exact in binary16.  Changing to AVX512\n";
             G.hashVariant = RAISR_HIP_HASH_AVX512;
             std::cout << "ASM Type: HIP gfx950 (AVX512-exact numerics)\n";
         }

@@ -2199,7 +2199,11 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     Q.bank16_bytes = (int)blob_f16_bytes(rows);
     Q.tab16 = c->d_tab16;
     Q.qangle = m.h.qangle16; Q.qs0 = m.h.qstr16[0]; Q.qs1 = m.h.qstr16[1]; Q.qc0 = m.h.qcoh16[0]; Q.qc1 = m.h.qcoh16[1];
-    { volatile float nf = 1.0f / (255.0f * 255.0f * 2.0f * 2.0f); Q.nf = nf; }
+    {   // NF_8 / NF_10 (Raisr_globals.h:208-209; Raisr_AVX512FP16.cpp:146-151)
+        const float maxv = c->cfg.bits == 8 ? 255.0f : 1023.0f;
+        volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
+        Q.nf = nf;
+    }
     Q.c_avx = (W - 1) - ((W - 1) % 32) + 1;
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
@@ -2536,8 +2540,8 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512 &&
         cfg->hash_variant != RAISR_HIP_HASH_FP16)
         return fail(RAISR_HIP_EINVAL, "unknown hash variant");
-    if (cfg->hash_variant == RAISR_HIP_HASH_FP16 && cfg->bits != 8)
-        return fail(RAISR_HIP_EINVAL, "the binary16 pipeline supports 8-bit content only");
+    if (cfg->hash_variant == RAISR_HIP_HASH_FP16 && cfg->bits > 10)
+        return fail(RAISR_HIP_EINVAL, "the binary16 pipeline supports 8- and 10-bit content (16-bit samples are not exact in binary16)");
     if (cfg->blending != RAISR_HIP_BLEND_COUNT && cfg->blending != RAISR_HIP_BLEND_RANDOMNESS)
         return fail(RAISR_HIP_EINVAL, "blending must be 1 (Randomness) or 2 (CountOfBitsChanged)");
     if (!c->model[0].valid || (cfg->passes == 2 && !c->model[1].valid)) return fail(RAISR_HIP_ESTATE, "model not set");
