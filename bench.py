@@ -269,6 +269,25 @@ def filtered_zone_px(w, h):
     return max(0, c_final - 6) * max(0, h - 12)
 
 
+class _stdout_to_stderr:
+    """The library prints the reference's banner / [RAISR ...] messages on the C stdout (buffered when piped): keep them off
+    this process's stdout, where the ONE JSON line goes."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def end_to_end_leg(R, wl, n_frames, gpu):
     """Reference methodology (docs/performance.md:8-13): host yuv planes in, host yuv planes out, one synchronous
     RNLHandler_Process per frame, Y + U + V, PCIe inclusive."""
@@ -282,7 +301,8 @@ def end_to_end_leg(R, wl, n_frames, gpu):
     ou = np.zeros((int(ch * ratio), int(cw * ratio)), u.dtype)
     ov = np.zeros_like(ou)
     R.RNLHandler_SetOpenCLContext(0, gpu)
-    rc = R.RNLHandler_Init(wl.folder, ratio, wl.bits, R.VideoRange, 20, R.HIP if wl.asm == 2 else wl.asm, wl.passes, wl.mode)
+    with _stdout_to_stderr():
+        rc = R.RNLHandler_Init(wl.folder, ratio, wl.bits, R.VideoRange, 20, R.HIP if wl.asm == 2 else wl.asm, wl.passes, wl.mode)
     if rc != R.RNLErrorNone:
         raise RuntimeError(f"RNLHandler_Init rc={rc:#x}")
     try:
@@ -555,6 +575,8 @@ def main():
             "cpu_baseline": cpu,
         }
         line.update(extras)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                       # nothing buffered by the C runtime may follow the JSON line
         print(json.dumps(line), flush=True)
     else:
         for d in lanes:

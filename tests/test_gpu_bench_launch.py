@@ -36,6 +36,7 @@ def test_bench_plain_contract_fields():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _one_json_line(out.stdout)
+    assert out.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line of stdout"
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "c3_2pass", "end_to_end", "parity"):
         assert k in j, k
