@@ -85,3 +85,29 @@ def test_exact_kernel_still_selectable(monkeypatch):
     finally:
         dev.close()
     assert np.array_equal(out, oracle_y(y, case))
+
+
+def test_full_size_self_check_c2():
+    """BASELINE config 2 at full size, four frame kinds: self-check mode (every pixel through both paths) finds no certified
+    bucket that differs from the exact one, and the production mode's output equals the oracle's."""
+    import raisr_hip as R
+    case = ("x", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False)
+    w, h = 1920, 1080
+    fr = _frames(w, h, 8)
+    for kind in ("natural", "random", "smooth", "edges"):
+        y = fr[kind]
+        ref = oracle_y(y, case)
+        for check in (True, False):
+            dev = R.RaisrDevice(0)
+            try:
+                dev.set_model_from_folder(folder(case[1]), 8, 1)
+                dev.configure(w, h, 2 * w, 2 * h, bits=8, passes=1, hash_variant=2)
+                dev.certify_debug(True, check)
+                out = np.zeros((2 * h, 2 * w), np.uint8)
+                dev.process_host(np.ascontiguousarray(y), out)
+                st = dev.certify_stats()
+            finally:
+                dev.close()
+            assert st["mismatches"] == 0 and st["pixels"] == 3824 * 2148, (kind, check, st)
+            assert np.array_equal(out, ref), (kind, check)
+        print(kind, "fallback fraction", round(st["uncertain"] / st["pixels"], 5))
