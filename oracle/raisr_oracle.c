@@ -290,15 +290,17 @@ static int hash_pixel(float a, float b, float d, const ora_pass_t *P, int avx2_v
  * ------------------------------------------------------------------------------------------ */
 static float dot_patch(const float *L, int W, int r, int c, const float *f)
 {
-    /* pixbuf[128] / filter row padded to 128 with +0 (Raisr.cpp:1056, :329-331) */
-    float pb[128], fb[128], acc[16];
-    for (int i = 0; i < PATCH; i++)
-        for (int j = 0; j < PATCH; j++) pb[i * PATCH + j] = L[(size_t)(r - PM + i) * W + (c - PM + j)];
-    for (int k = 0; k < TAPS; k++) fb[k] = f[k];
-    for (int k = TAPS; k < 128; k++) { pb[k] = 0.0f; fb[k] = 0.0f; }
-    for (int l = 0; l < 16; l++) acc[l] = pb[l] * fb[l];
-    for (int ch = 1; ch < 8; ch++)
-        for (int l = 0; l < 16; l++) acc[l] = fmaf(pb[16 * ch + l], fb[16 * ch + l], acc[l]);
+    /* pixbuf[128] / filter row padded to 128 with +0 (Raisr.cpp:1056, :329-331).  The patch is gathered row by row (11
+     * contiguous floats each); the filter row is used in place for the seven full chunks and copied only for the last,
+     * partly padded one.  Same 16 accumulator chains, same order: acc[l] = p[l]*f[l]; acc[l] = fma(p[16c+l], f[16c+l], acc[l]). */
+    float pb[128] __attribute__((aligned(64))), ft[16] __attribute__((aligned(64))), acc[16] __attribute__((aligned(64)));
+    for (int i = 0; i < PATCH; i++) memcpy(pb + i * PATCH, L + (size_t)(r - PM + i) * W + (c - PM), PATCH * sizeof(float));
+    for (int k = TAPS; k < 128; k++) pb[k] = 0.0f;
+    for (int l = 0; l < 16; l++) ft[l] = (112 + l < TAPS) ? f[112 + l] : 0.0f;
+    for (int l = 0; l < 16; l++) acc[l] = pb[l] * f[l];
+    for (int ch = 1; ch < 7; ch++)
+        for (int l = 0; l < 16; l++) acc[l] = fmaf(pb[16 * ch + l], f[16 * ch + l], acc[l]);
+    for (int l = 0; l < 16; l++) acc[l] = fmaf(pb[112 + l], ft[l], acc[l]);
     float t[8], u[4];
     for (int i = 0; i < 8; i++) t[i] = acc[i] + acc[i + 8];
     for (int i = 0; i < 4; i++) u[i] = t[i] + t[i + 4];
@@ -391,26 +393,30 @@ void ora_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t *o
         for (int c = 0; c < W; c++) { out[c] = lr[c]; out[(size_t)(H - 1) * W + c] = lr[(size_t)(H - 1) * W + c]; }
         for (int r = 0; r < H; r++) { out[(size_t)r * W] = lr[(size_t)r * W]; out[(size_t)r * W + W - 1] = lr[(size_t)r * W + W - 1]; }
         #pragma omp parallel for schedule(static)
-        for (int r = 1; r < H - 1; r++)                            /* Raisr_AVX256.cpp:78-165 */
+        for (int r = 1; r < H - 1; r++) {                          /* Raisr_AVX256.cpp:78-165 */
+            /* the eight neighbours written out, so that the column loop is a flat loop the compiler vectorises */
+            const float *l0 = L + (size_t)(r - 1) * W, *l1 = L + (size_t)r * W, *l2 = L + (size_t)(r + 1) * W;
+            const float *h0 = HR + (size_t)(r - 1) * W, *h1 = HR + (size_t)r * W, *h2 = HR + (size_t)(r + 1) * W;
+            uint16_t *o = out + (size_t)r * W;
+            const int ilo = P->lo, ihi = P->hi;
             for (int c = 1; c < W - 1; c++) {
-                size_t idx = (size_t)r * W + c;
+                const float lc = l1[c], hc = h1[c];
                 int hd = 0;
-                for (int i = -1; i <= 1; i++)
-                    for (int j = -1; j <= 1; j++) {
-                        if (!i && !j) continue;
-                        size_t nn = (size_t)(r + i) * W + c + j;
-                        int bl = L[nn] < L[idx], bh = HR[nn] < HR[idx];
-                        hd += abs(bl - bh);
-                    }
+#define ORA_CT(ln, hn) hd += ((ln) < lc) != ((hn) < hc)
+                ORA_CT(l0[c - 1], h0[c - 1]); ORA_CT(l0[c], h0[c]); ORA_CT(l0[c + 1], h0[c + 1]);
+                ORA_CT(l1[c - 1], h1[c - 1]);                       ORA_CT(l1[c + 1], h1[c + 1]);
+                ORA_CT(l2[c - 1], h2[c - 1]); ORA_CT(l2[c], h2[c]); ORA_CT(l2[c + 1], h2[c + 1]);
+#undef ORA_CT
                 float weight = (float)hd / 8.0f;
                 float w2 = 1.0f - weight;
-                float val = (weight * L[idx]) + (w2 * HR[idx]);
+                float val = (weight * lc) + (w2 * hc);
                 val = val + 0.5f;
                 int32_t iv = cvt_rne_x86(floorf(val));
-                if (iv > P->hi) iv = P->hi;
-                if (iv < P->lo) iv = P->lo;
-                out[idx] = (uint16_t)iv;
+                if (iv > ihi) iv = ihi;
+                if (iv < ilo) iv = ilo;
+                o[c] = (uint16_t)iv;
             }
+        }
     }
     if (hr_dump) memcpy(hr_dump, HR, n * sizeof(float));
     free(L); free(HR);
