@@ -85,8 +85,8 @@ def test_loud_failures():
     dev.set_model_from_folder(folder("filters_2x/filters_highres"), 8, 1)
     with pytest.raises(RuntimeError, match="pixel types"):
         dev.configure(64, 64, 96, 96, ratio2=False)
-    with pytest.raises(RuntimeError, match="8-bit"):
-        dev.configure(64, 64, 128, 128, bits=10, hash_variant=R.HASH_FP16)
+    with pytest.raises(RuntimeError, match="binary16"):      # 16-bit samples are not exact in binary16 (8 and 10 bit are supported)
+        dev.configure(64, 64, 128, 128, bits=16, full_range=True, hash_variant=R.HASH_FP16)
     dev.close()
 
 

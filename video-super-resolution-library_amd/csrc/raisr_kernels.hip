@@ -91,18 +91,7 @@ struct PassParams {
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
-    unsigned long long* prof;    // profiling aid: shader-clock cycles per phase of the certified hash stage, summed over tiles (or null)
 };
-
-// phase stamps of wave 0 / lane 0 (only when P.prof is set: RAISR_HIP_PHASES=1)
-#define RAISR_STAMP(P, slot, t_prev)                                                             \
-    do {                                                                                         \
-        if ((P).prof && threadIdx.x == 0) {                                                      \
-            const unsigned long long _t = clock64();                                             \
-            atomicAdd(&(P).prof[slot], _t - (t_prev));                                           \
-            (t_prev) = _t;                                                                       \
-        }                                                                                        \
-    } while (0)
 
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
 // each XCD has a private 4 MiB L2, so with the plain (blockIdx.x, blockIdx.y) order the eight tiles around
@@ -868,14 +857,13 @@ constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilte
 template <int LW, typename GT>
 __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, float4* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
-                                              int c0, int r0, unsigned long long& tstamp)
+                                              int c0, int r0)
 {
     constexpr int GW_ = 74, TW = 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) sCnt[0] = 0;
     float ta[4], tb[4], td[4];
     tensor_ac(S, sG, sV, ta, tb, td);
-    RAISR_STAMP(P, 3, tstamp);
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
@@ -909,9 +897,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     if (P.cert_stats) {
         if (nUnc) atomicAdd(&sCnt[1], nUnc);
     }
-    RAISR_STAMP(P, 4, tstamp);
     __syncthreads();
-    RAISR_STAMP(P, 5, tstamp);
 
     // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
@@ -953,9 +939,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         }
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
-    RAISR_STAMP(P, 6, tstamp);
     if (n) __syncthreads();                                // (n is the same in every thread)
-    RAISR_STAMP(P, 7, tstamp);
 }
 
 #include "raisr_fp16_kernels.h"
@@ -1176,12 +1160,10 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-    unsigned long long tstamp = P.prof ? clock64() : 0ull;
     if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
     if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
-    RAISR_STAMP(P, 0, tstamp);
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
@@ -1202,8 +1184,7 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
         }
     }
     __syncthreads();
-    RAISR_STAMP(P, 1, tstamp);
-    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tstamp);
+    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0);
     else {
         for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)((i * 7) % 216); sH2[i] = 0xFFu; }
         __syncthreads();
@@ -1224,7 +1205,6 @@ __global__ __launch_bounds__(256, 3) void k_hashfilter_ac(const T* __restrict__ 
     }
     if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
     else if (sH[threadIdx.x] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
-    RAISR_STAMP(P, 8, tstamp);
 }
 
 
@@ -1989,7 +1969,6 @@ struct raisr_hip_ctx {
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
     FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
     size_t fix_tiles = 0;
-    unsigned long long* d_prof = nullptr;      // RAISR_HIP_PHASES=1: per-phase shader-clock cycles of the certified hash stage
     int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
     unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
     SepW sep{};
@@ -2089,7 +2068,6 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.lut_legacy = c->d_lut;
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
     P.gauss_dev = c->d_gauss;
-    P.prof = c->d_prof;
     return P;
 }
 
@@ -2349,10 +2327,6 @@ static int create_impl(raisr_hip_ctx* c)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     }
     HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
-    if (const char* e = getenv("RAISR_HIP_PHASES")) if (atoi(e)) {
-        HIP_TRY(hipMalloc((void**)&c->d_prof, 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
-    }
     int rc = pool_get_stream(c->device, &c->stream);
     if (rc) return rc;
     rc = pool_get_stream(c->device, &c->stream2);
@@ -2412,14 +2386,6 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
     if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
     if (c->d_gauss) (void)hipFree(c->d_gauss);
-    if (c->d_prof) {
-        unsigned long long h[16];
-        if (hipMemcpy(h, c->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[0]) {
-            fprintf(stderr, "[raisr-hip phases] cycles of wave 0 per phase, summed over tiles: stage %llu grad %llu vpass %llu hpass %llu hash %llu barrier %llu fixup %llu barrier %llu filter %llu\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
-        }
-        (void)hipFree(c->d_prof);
-    }
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
     pool_put_stream(c->device, c->stream);
     pool_put_stream(c->device, c->stream2);
