@@ -197,6 +197,13 @@ int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash
  * Replaces nothing in the reference; it is the observability of an optimisation the reference does not have. */
 int raisr_hip_debug_certify(raisr_hip_ctx *ctx, int collect, int check);
 int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[3]);
+/* Decision of the certified hash stage for `n` host-side APPROXIMATE tensor triples (a', b', d'): the bucket it computes and
+ * whether it certifies it (1) or would send the pixel to the exact path (0), by the device function the kernels run.
+ * *eps_out (optional) receives the relative tensor error eps the certification assumes: a certified bucket must equal the
+ * reference hash of EVERY exact tensor with |a-a'| <= eps a', |d-d'| <= eps d', |b-b'| <= eps (a'+d')/2
+ * (tests/test_gpu_certify.py samples that box).  Needs a configured context (the weights depend on the bit depth). */
+int raisr_hip_debug_approx_hash(raisr_hip_ctx *ctx, int pass_index, int hash_flavour, const float *abd, size_t n,
+                                uint8_t *bucket_out, uint8_t *cert_out, float *eps_out);
 /* Hash bucket (0..215) of `n` host-side structure-tensor triples (a, b, d) x n with pass `pass_index`'s
  * thresholds, computed by the very device functions the hash kernel runs (fast path plus generic fall-back
  * for RAISR_HIP_HASH_AVX512; the RCPPS/RSQRTPS flavour for RAISR_HIP_HASH_AVX2).  Replaces nothing in the

@@ -111,3 +111,62 @@ def test_full_size_self_check_c2():
             assert st["mismatches"] == 0 and st["pixels"] == 3824 * 2148, (kind, check, st)
             assert np.array_equal(out, ref), (kind, check)
         print(kind, "fallback fraction", round(st["uncertain"] / st["pixels"], 5))
+
+
+@pytest.mark.parametrize("flavour", [2, 1], ids=["avx512", "avx2"])
+def test_certified_buckets_hold_on_the_whole_error_box(flavour):
+    """The certification claim itself, away from images: for adversarial approximate tensors (a', b', d') -- all scales,
+    near-isotropic, near-axis, near every threshold -- a bucket the device certifies must equal the oracle's exact hash of
+    EVERY tensor in the error box |a-a'| <= eps a', |d-d'| <= eps d', |b-b'| <= eps (a'+d')/2.  The box is sampled at its 8
+    corners, its centre and 7 random interior points per triple."""
+    import oracle_py as O
+    import raisr_hip as R
+    rng = np.random.default_rng(20260928 + flavour)
+    fold = "filters_2x/filters_highres"
+    m = O.Model(folder(fold), 8, 1)
+    P = O.make_pass(m, 8, False, O.ASM_AVX512)
+    n = 400000
+    scale = np.exp(rng.uniform(np.log(3e-10), np.log(0.3), n))
+    # tensors (a, b, d) = rotation of eigenvalues (l1 >= l2 >= 0): anisotropy from degenerate to isotropic, all angles,
+    # a third of the angles snapped next to a bucket boundary, a third of the strengths / coherences next to a threshold
+    theta = rng.uniform(0, np.pi, n)
+    snap = rng.random(n) < 0.33
+    theta = np.where(snap, np.round(theta * 24 / np.pi) * np.pi / 24 + rng.normal(0, 3e-4, n), theta)
+    ratio = np.where(rng.random(n) < 0.3, np.exp(rng.uniform(np.log(1e-7), 0, n)), rng.uniform(0, 1, n))     # l2 / l1
+    qc = np.array([P.qcoh[0], P.qcoh[1]], np.float64)
+    near_c = rng.random(n) < 0.25
+    tq = (1 - qc[rng.integers(0, 2, n)]) / (1 + qc[rng.integers(0, 2, n)])
+    ratio = np.where(near_c, np.clip(tq * tq * (1 + rng.normal(0, 5e-4, n)), 0, 1), ratio)
+    l1 = scale
+    qs = np.array([P.qstr[0], P.qstr[1]], np.float64)
+    near_s = rng.random(n) < 0.25
+    l1 = np.where(near_s, qs[rng.integers(0, 2, n)] * (1 + rng.normal(0, 5e-4, n)), l1)
+    l2 = l1 * ratio
+    cth, sth = np.cos(theta), np.sin(theta)
+    a = l1 * cth * cth + l2 * sth * sth
+    d = l1 * sth * sth + l2 * cth * cth
+    b = (l1 - l2) * sth * cth
+    abd = np.stack([a, b, d], 1).astype(np.float32)
+    dev = R.RaisrDevice(0)
+    try:
+        dev.set_model_from_folder(folder(fold), 8, 1)
+        dev.configure(64, 64, 128, 128, bits=8)
+        bucket, cert, eps = dev.debug_approx_hash(abd, 0, R.HASH_AVX512 if flavour == 2 else R.HASH_AVX2)
+    finally:
+        dev.close()
+    assert 1e-6 < eps < 2e-5, eps
+    frac = cert.mean()
+    assert 0.2 < frac < 0.98, frac                     # the adversarial mix must exercise both outcomes
+    sel = np.nonzero(cert)[0]
+    A = abd[sel].astype(np.float64)
+    T = A[:, 0] + A[:, 2]
+    bad_total = 0
+    signs = [(sa, sb, sd) for sa in (-1, 1) for sb in (-1, 1) for sd in (-1, 1)] + [(0, 0, 0)]
+    pts = [np.array(s3, np.float64) for s3 in signs] + [rng.uniform(-1, 1, 3) for _ in range(7)]
+    for sg in pts:
+        X = np.stack([A[:, 0] * (1 + sg[0] * eps * 0.999), A[:, 1] + sg[1] * eps * 0.999 * T / 2, A[:, 2] * (1 + sg[2] * eps * 0.999)], 1).astype(np.float32)
+        hx = O.hash_array(X, P, flavour == 1)
+        bad = hx != bucket[sel]
+        bad_total += int(bad.sum())
+        assert not bad.any(), (sg.tolist(), int(bad.sum()), abd[sel][bad][:3].tolist(), X[bad][:3].tolist(), bucket[sel][bad][:3].tolist(), hx[bad][:3].tolist())
+    assert bad_total == 0

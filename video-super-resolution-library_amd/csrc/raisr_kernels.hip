@@ -942,6 +942,22 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     if (n) __syncthreads();                                // (n is the same in every thread)
 }
 
+// Test hook: the certified hash stage's decision for arbitrary APPROXIMATE tensor triples (a', b', d'): bucket and whether
+// it would be certified, by the very approx_hash the kernels run (flavour 0: AVX-512 table error, 1: AVX2).
+__global__ __launch_bounds__(256) void k_debug_approx_hash(const float* __restrict__ abd, unsigned n, PassParams P, SepW S, int fl,
+                                                           uint8_t* __restrict__ bucket_out, uint8_t* __restrict__ cert_out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    const float a = abd[3 * (size_t)i], b = abd[3 * (size_t)i + 1], d = abd[3 * (size_t)i + 2];
+    unsigned bucket;
+    bool cert = approx_hash(a, b, d, Q, S, fl, bucket);
+    if ((a + d) == 0.0f) { cert = true; bucket = (unsigned)P.zero_bucket[fl]; }
+    bucket_out[i] = (uint8_t)bucket;
+    cert_out[i] = cert ? 1 : 0;
+}
+
 #include "raisr_fp16_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -2839,6 +2855,34 @@ int raisr_hip_debug_certify_stats(raisr_hip_ctx* c, unsigned out[3])
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_cert_stats, 3 * sizeof(unsigned), hipMemcpyDeviceToHost));
     return RAISR_HIP_OK;
+}
+
+// Test hook: decision of the certified hash stage for n host-side approximate tensor triples (see include/raisr_hip.h).
+int raisr_hip_debug_approx_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, const float* abd, size_t n,
+                                uint8_t* bucket_out, uint8_t* cert_out, float* eps_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1 || !abd || !bucket_out || !cert_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (hash_flavour != RAISR_HIP_HASH_AVX512 && hash_flavour != RAISR_HIP_HASH_AVX2) return fail(RAISR_HIP_EINVAL, "hash_flavour must be AVX512 or AVX2");
+    if (!c->model[pass_index].blob || !c->configured) return fail(RAISR_HIP_ESTATE, "set the model and configure first");
+    if (eps_out) *eps_out = c->sep.eEb * 2.0f;             // the eps of the tensor bounds (eEb = eps / 2)
+    if (n == 0) return RAISR_HIP_OK;
+    if (n > 0x7fffffffu / 3) return fail(RAISR_HIP_EINVAL, "too many triples");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, 2 * n) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc) {
+        hipLaunchKernelGGL(k_debug_approx_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P, c->sep,
+                           hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out, d_out + n);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_approx_hash");
+    }
+    if (!rc && (hipMemcpy(bucket_out, d_out, n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(cert_out, d_out + n, n, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
 }
 
 // Test hook: hash bucket of n host-side (a, b, d) triples with pass `pass_index`'s thresholds, computed by the

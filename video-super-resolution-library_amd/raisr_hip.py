@@ -121,6 +121,8 @@ def lib():
         L.raisr_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.raisr_hip_host_unregister.argtypes = [ctypes.c_void_p]
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -342,6 +344,15 @@ class RaisrDevice:
         out = np.zeros(abd.shape[0], np.uint8)
         _check(lib().raisr_hip_debug_hash(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
         return out
+
+    def debug_approx_hash(self, abd, pass_index=0, flavour=HASH_AVX512):
+        """(bucket, certified, eps) of the certified hash stage for an (n, 3) float32 array of approximate tensor triples."""
+        abd = np.ascontiguousarray(abd, np.float32)
+        n = abd.shape[0]
+        bucket = np.zeros(n, np.uint8); cert = np.zeros(n, np.uint8); eps = ctypes.c_float()
+        _check(lib().raisr_hip_debug_approx_hash(self._h, pass_index, flavour, abd.ctypes.data, n, bucket.ctypes.data, cert.ctypes.data,
+                                                 ctypes.byref(eps)), "debug_approx_hash")
+        return bucket, cert.astype(bool), float(eps.value)
 
     def certify_debug(self, collect=True, check=False):
         """Certified hash stage: start (and zero) / stop the statistics; check=True also runs the exact path for every pixel."""
