@@ -21,7 +21,9 @@ and, at N = 1 (outside the timed region of `value`, never mixed into it):
                   the reference's own methodology, docs/performance.md:8-13)
   stream       -- host planes -> host planes through the library's pinned-ring batch entry (uploads, kernels and
                   downloads of neighbouring frames overlapped)
-  parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR.
+  parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR
+  fast_mode    -- the opt-in, NOT bit-exact matrix-core filter stage (raisr_hip_set_fast(2)): the same loop, with its
+                  distance from the oracle beside it.  Never the headline.
 """
 import argparse
 import hashlib
@@ -214,7 +216,7 @@ def respawn_ranks(args):
     os.execv(sys.executable, cmd)
 
 
-def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmup, fence, timing):
+def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmup, fence, timing, fast=None):
     """Frames resident in HBM -> output planes in HBM, `lanes_n` frames in flight.  Returns (seconds, kernel timings,
     lanes, device inputs/outputs)."""
     dev = torch.device("cuda", gpu)
@@ -224,6 +226,8 @@ def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmu
         for p in range(wl.passes):
             d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
         d.configure(wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode, hash_variant=wl.asm)
+        if fast is not None:
+            d.set_fast(fast)
         lanes.append(d)
     d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
     d_out = [torch.empty((wl.out_h, wl.out_w), dtype=torch.uint8 if wl.bps == 1 else torch.uint16, device=dev) for _ in range(lanes_n)]
@@ -383,7 +387,7 @@ def stream_leg(R, wl, gpu, n_frames, collect_outputs=0):
     return (res, kept) if collect_outputs else res
 
 
-def parity_leg(R, wl, gpu, blobs, kind):
+def parity_leg(R, wl, gpu, blobs, kind, fast=None):
     """One frame of the workload, HIP vs the CPU oracle (the checker, never the thing measured)."""
     import torch
     frame = wl.frames(kind, [0])[0]
@@ -393,6 +397,8 @@ def parity_leg(R, wl, gpu, blobs, kind):
     for p in range(wl.passes):
         d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
     d.configure(wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode, hash_variant=wl.asm)
+    if fast is not None:
+        d.set_fast(fast)
     out = np.zeros((wl.out_h, wl.out_w), frame.dtype)
     d.process_host(frame, out)
     d.close()
@@ -527,6 +533,7 @@ def main():
                                     # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
                                     "sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)}
                 roofline["binding"] = "fp32-valu"
+        fast_level = lanes[0].fast() if lanes and hasattr(lanes[0], "fast") else int(os.environ.get("RAISR_HIP_FAST", "0") or 0)
         for d in lanes:
             d.close()
         extras = {}
@@ -552,6 +559,19 @@ def main():
             if hasattr(R, "RaisrStream"):
                 leg("stream", lambda: stream_leg(R, wl, gpu, args.extra_frames))
             leg("parity", lambda: parity_leg(R, wl, gpu, blobs, args.frame_kind))
+            if wl.pixel_types == 4 and wl.bits <= 10 and wl.asm != 5 and hasattr(R.RaisrDevice, "set_fast"):
+                def fast_leg():
+                    # NOT a parity path and never the headline: the opt-in matrix-core filter stage, same loop as `value`
+                    n = args.extra_frames
+                    dtf, _, lf, _, _ = device_loop(R, torch, wl, gpu, blobs, args.lanes, wl.frames(args.frame_kind, range(8)), n, 1, 1, fence, False, fast=2)
+                    for d in lf:
+                        d.close()
+                    par = parity_leg(R, wl, gpu, blobs, args.frame_kind, fast=2)
+                    return {"value": round(wl.out_w * wl.out_h * n / dtf / 1e6, 2), "unit": "MP/s", "fps": round(n / dtf, 2), "frames": n,
+                            "bit_exact": False, "differing_pixels": par["mismatches"], "max_abs_diff": par["max_abs_diff"], "psnr_vs_oracle": par["psnr"],
+                            "what": "raisr_hip_set_fast(2): approximate-tensor buckets without the exact re-hash + 121-tap filter on the matrix "
+                                    "cores (binary16 coefficients); off by default"}
+                leg("fast_mode", fast_leg)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -565,7 +585,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl.name}: {wl.desc}, CT blend, {where}" + (f" [passes={wl.passes}]" if args.passes else ""),
-                       "frame_kind": args.frame_kind,
+                       "frame_kind": args.frame_kind, "mode": "exact" if not fast_level else f"fast-{fast_level} (NOT bit-exact: RAISR_HIP_FAST is set)",
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "timed_region_s": round(dt, 3),
                        "parallelism": f"frame-shard x{world}"},

@@ -180,6 +180,16 @@ void raisr_hip_host_free(void *p);
 int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns */
 int  raisr_hip_host_unregister(void *p);
 
+/* NON-bit-exact fast mode (north_star's MFMA question; off by default, RAISR_HIP_FAST=1 turns it on at
+ * create time).  The buckets stay exact (certified hash stage); the 121-tap dot product of DotProdPatch_AVX512_32f
+ * (Raisr_AVX512.cpp:134-149) runs on the matrix cores with binary16 coefficients and the MFMA's own fp32 summation order,
+ * and the AVX2 re-hash of the tail columns (Raisr.cpp:1247-1250) is not applied.  Output differs from the exact mode by
+ * rounding noise (measured in DESIGN.md s5; tests/test_gpu_fast_mode.py bounds it).  Supported: ratio 2, 8/10-bit content,
+ * asm avx2/avx512; anything else is refused here (configured context) or by raisr_hip_configure.  Replaces nothing in the
+ * reference, which has no such mode. */
+int raisr_hip_set_fast(raisr_hip_ctx *ctx, int on);
+int raisr_hip_get_fast(const raisr_hip_ctx *ctx);
+
 /* Introspection for tests / profiling ---------------------------------------------------------
  * Copies the last frame's per-pixel hash plane (u8: bucket 0..215 of the first hash, stale outside the
  * filtered zone) and HR plane (fp32; binary16 bit patterns in the low half-words in FP16 mode) of pass

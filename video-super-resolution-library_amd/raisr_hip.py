@@ -124,6 +124,8 @@ def lib():
         L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_get_fast.argtypes = [ctypes.c_void_p]
         L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -353,6 +355,14 @@ class RaisrDevice:
         _check(lib().raisr_hip_debug_approx_hash(self._h, pass_index, flavour, abd.ctypes.data, n, bucket.ctypes.data, cert.ctypes.data,
                                                  ctypes.byref(eps)), "debug_approx_hash")
         return bucket, cert.astype(bool), float(eps.value)
+
+    def set_fast(self, on=1):
+        """NON-bit-exact fast mode. 1: exact buckets, filter stage on the matrix cores (binary16 coefficients);
+        2: also keeps the approximate tensor's bucket where the hash stage cannot certify it (no exact re-hash)."""
+        _check(lib().raisr_hip_set_fast(self._h, int(on)), "set_fast")
+
+    def fast(self):
+        return int(lib().raisr_hip_get_fast(self._h))
 
     def certify_debug(self, collect=True, check=False):
         """Certified hash stage: start (and zero) / stop the statistics; check=True also runs the exact path for every pixel."""
