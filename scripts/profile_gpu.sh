@@ -20,4 +20,6 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_I
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $PMC > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $PMC > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -- $PMC > "$OUT/pmc_l2.log" 2>&1
+# matrix-core counters (only the opt-in fast mode issues MFMAs)
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES -d "$OUT/pmc_mfma" -- $PMC > "$OUT/pmc_mfma.log" 2>&1
 echo done

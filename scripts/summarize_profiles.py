@@ -40,7 +40,7 @@ if os.path.exists(ev):
     except Exception as e:
         lines += [f"(bench_events.json unreadable: {e})", ""]
 pmc = {}
-for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_l2"):
+for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_mfma"):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
