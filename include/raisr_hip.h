@@ -84,6 +84,13 @@ int    raisr_hip_pack_model_blob(void *host_blob, const float *bank, int hashkey
 int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const void *device_blob,
                                        size_t bytes, void *stream);
 
+/* Multi-GPU start-up (one process per GPU): in-place RCCL broadcast of a packed model blob that lives in device
+ * memory, from rank `root` to every rank of the communicator `nccl_comm` (an ncclComm_t), stream-ordered on `stream`
+ * (hipStream_t or NULL).  Every rank then calls raisr_hip_set_model_blob_device() on its copy.  This is the path's only
+ * collective; librccl.so is loaded on first use, so single-GPU consumers carry no RCCL dependency.  The reference is a CPU
+ * library and has no counterpart; bench.py / sharding.py issue the same broadcast through torch.distributed. */
+int    raisr_hip_broadcast_model_blob(void *nccl_comm, int root, void *device_blob, size_t bytes, void *stream);
+
 /* Geometry / resources ------------------------------------------------------------------------ */
 int raisr_hip_configure(raisr_hip_ctx *ctx, const raisr_hip_config *cfg);
 

@@ -40,6 +40,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -2702,6 +2703,36 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     HIP_TRY(hipStreamSynchronize(s));
     m.bytes = bytes; m.h = h; m.valid = true; m.bank_mfma_valid = false;
     return compute_zero_buckets(c, pass_index);
+}
+
+// Multi-GPU start-up: the one collective of the path.  RCCL is resolved on first use, so a single-GPU consumer of
+// this library carries no librccl dependency; the handful of declarations below are RCCL's stable C ABI (rccl.h).
+int raisr_hip_broadcast_model_blob(void* nccl_comm, int root, void* device_blob, size_t bytes, void* stream)
+{
+    if (!nccl_comm || !device_blob || bytes < (size_t)kBlobHeader || root < 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    static std::mutex mu;
+    static bcast_fn bcast = nullptr;
+    static errstr_fn errstr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!bcast) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return fail(RAISR_HIP_ERUNTIME, "librccl.so not found (needed only for the multi-GPU model broadcast)");
+            bcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
+            errstr = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+            if (!bcast) return fail(RAISR_HIP_ERUNTIME, "ncclBroadcast not exported by librccl");
+        }
+    }
+    const int kNcclUint8 = 1;                                         // ncclDataType_t
+    const int rc = bcast(device_blob, device_blob, bytes, kNcclUint8, root, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) {
+        g_err = std::string("ncclBroadcast: ") + (errstr ? errstr(rc) : "error");
+        return RAISR_HIP_ERUNTIME;
+    }
+    return RAISR_HIP_OK;
 }
 
 int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,

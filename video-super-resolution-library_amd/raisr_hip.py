@@ -125,6 +125,7 @@ def lib():
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_broadcast_model_blob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_get_fast.argtypes = [ctypes.c_void_p]
         L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
