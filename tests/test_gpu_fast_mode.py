@@ -136,3 +136,22 @@ def test_fast_mode_refuses_what_it_does_not_support(monkeypatch):
             dev.configure(120, 80, 240, 160, bits=8, passes=1, hash_variant=5)
     finally:
         dev.close()
+
+
+def test_fast_mode_through_the_plugin_api_is_an_environment_switch(monkeypatch):
+    """An FFmpeg user has no C call to make: RAISR_HIP_FAST, read when the handler creates its context, selects the mode.
+    1.5x is refused at SetRes with the library's error convention, 2x runs and lands within the mode's budget."""
+    import raisr_hip as R
+    import synth
+    monkeypatch.setenv("RAISR_HIP_FAST", "2")
+    y = synth.natural_y(320, 180, 8, seed=21)
+    c = synth.chroma(160, 90, 8)
+    oy, ou, ov = R.upscale_frame_host(y, c, c, folder("filters_2x/filters_highres"), ratio=2.0, bits=8, asm_type=R.AVX512)
+    ref = oracle_y(y, CASES[0])
+    assert not np.array_equal(oy, ref) and _psnr(oy, ref, 8) > 48.0
+    with pytest.raises(Exception):
+        R.upscale_frame_host(synth.natural_y(96, 64, 8, seed=4), synth.chroma(48, 32, 8), synth.chroma(48, 32, 8),
+                             folder("filters_1.5x/filters_highres"), ratio=1.5, bits=8, asm_type=R.AVX512)
+    monkeypatch.delenv("RAISR_HIP_FAST")
+    oy, _, _ = R.upscale_frame_host(y, c, c, folder("filters_2x/filters_highres"), ratio=2.0, bits=8, asm_type=R.AVX512)
+    assert np.array_equal(oy, ref)
