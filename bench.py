@@ -326,7 +326,7 @@ def end_to_end_leg(R, wl, n_frames, gpu):
             "what": "host->host yuv420p through RNLHandler_Process (synchronous, pageable caller planes, Y+U+V, PCIe inclusive)"}
 
 
-def stream_leg(R, wl, gpu, n_frames, collect_outputs=0):
+def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):
     """Host planes -> host planes through the library's ring (raisr_hip_stream_*): uploads, kernels and downloads of
     neighbouring frames overlap.  The planes are page-locked (raisr_hip_host_alloc), as a host with its own buffer pool would
     hand them over.  Returns the JSON object (and, for tests, copies of the first `collect_outputs` Y outputs)."""
@@ -351,7 +351,8 @@ def stream_leg(R, wl, gpu, n_frames, collect_outputs=0):
     pins.extend(frames_out)
     outs = [(f.y, f.u, f.v) for f in frames_out]
     st = R.RaisrStream(gpu, wl.folder, wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode,
-                       hash_variant=wl.asm, chroma=(cw, ch, ocw, och), depth=depth)
+                       hash_variant=wl.asm, chroma=(cw, ch, ocw, och), depth=depth,
+                       blobs=None if blobs is None else [(b.data_ptr(), b.numel()) for b in blobs])    # the broadcast blob, not the files
     kept = []
     try:
         for warm in (True, False):
@@ -480,7 +481,7 @@ def main():
         # region is the submit/collect loop over this rank's frames of all K steps (ring and page-locked planes set up outside)
         mine = sharding.frames_for_rank(nf * args.steps * world, rank, world)
         fence()
-        res = stream_leg(R, wl, gpu, len(mine))
+        res = stream_leg(R, wl, gpu, len(mine), blobs=blobs)
         dt = len(mine) / res["fps"]
         fence()
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
@@ -557,7 +558,7 @@ def main():
                 leg("c3_2pass", c3)
             leg("end_to_end", lambda: end_to_end_leg(R, wl, args.extra_frames, gpu))
             if hasattr(R, "RaisrStream"):
-                leg("stream", lambda: stream_leg(R, wl, gpu, args.extra_frames))
+                leg("stream", lambda: stream_leg(R, wl, gpu, args.extra_frames, blobs=blobs))
             leg("parity", lambda: parity_leg(R, wl, gpu, blobs, args.frame_kind))
             if wl.pixel_types == 4 and wl.bits <= 10 and wl.asm != 5 and hasattr(R.RaisrDevice, "set_fast"):
                 def fast_leg():

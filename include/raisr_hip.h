@@ -174,6 +174,9 @@ void raisr_hip_stream_destroy(raisr_hip_stream *s);
 int  raisr_hip_stream_depth(const raisr_hip_stream *s);
 int  raisr_hip_stream_set_model(raisr_hip_stream *s, int pass_index, const float *bank, int hashkeys, int pixel_types,
                                 const double qstr[2], const double qcoh[2], int quant_angle);
+int  raisr_hip_stream_set_model_blob_device(raisr_hip_stream *s, int pass_index, const void *device_blob, size_t bytes,
+                                            void *stream);                              /* after raisr_hip_broadcast_model_blob */
+int  raisr_hip_stream_set_fast(raisr_hip_stream *s, int level);                        /* raisr_hip_set_fast on every lane; nothing in flight */
 int  raisr_hip_stream_configure(raisr_hip_stream *s, const raisr_hip_config *cfg);
 int  raisr_hip_stream_submit(raisr_hip_stream *s,
                              const void *in_y, size_t in_y_pitch, void *out_y, size_t out_y_pitch,

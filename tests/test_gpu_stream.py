@@ -89,3 +89,37 @@ def test_packed_output_frame_is_downloaded_in_one_copy_and_matches():
     finally:
         st.close()
         fo.close()
+
+
+def test_stream_ring_from_a_device_blob_and_fast_passthrough():
+    """The multi-GPU start-up of a streamed rank: lanes take the packed blob from device memory (what the RCCL broadcast
+    delivers) instead of reading files; same bits.  set_fast reaches every lane and is refused while frames are in flight."""
+    import torch
+    import raisr_hip as R
+    import synth
+    from common import oracle_y
+    fold = "filters_2x/filters_highres"
+    w, h = 192, 108
+    bank, qstr, qcoh, qa = R.read_model_folder(folder(fold), 8, 1)
+    blob = torch.from_numpy(R.pack_model_blob(bank, qstr, qcoh, qa)).cuda()
+    st = R.RaisrStream(0, "/nonexistent", w, h, 2 * w, 2 * h, bits=8, depth=2, blobs=[(blob.data_ptr(), blob.numel())])
+    try:
+        ys = [synth.natural_y(w, h, 8, seed=70 + i) for i in range(3)]
+        outs = [np.zeros((2 * h, 2 * w), np.uint8) for _ in ys]
+        for y, o in zip(ys[:2], outs[:2]):
+            st.submit(y, None, None, o, None, None)
+        with pytest.raises(RuntimeError):
+            st.set_fast(1)                       # frames in flight
+        st.collect(); st.collect()
+        st.submit(ys[2], None, None, outs[2], None, None); st.collect()
+        case = ("x", fold, (2, 1), 8, 1, 1, 2, False)
+        for y, o in zip(ys, outs):
+            assert np.array_equal(o, oracle_y(y, case))
+        st.set_fast(1)
+        st.submit(ys[0], None, None, outs[0], None, None); st.collect()
+        assert not np.array_equal(outs[0], oracle_y(ys[0], case))
+        st.set_fast(0)
+        st.submit(ys[0], None, None, outs[0], None, None); st.collect()
+        assert np.array_equal(outs[0], oracle_y(ys[0], case))
+    finally:
+        st.close()

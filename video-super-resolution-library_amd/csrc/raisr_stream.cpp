@@ -64,6 +64,29 @@ int raisr_hip_stream_set_model(raisr_hip_stream* s, int pass_index, const float*
     return RAISR_HIP_OK;
 }
 
+// Multi-GPU streams (BASELINE C5): the rank received the packed blob by raisr_hip_broadcast_model_blob; every lane copies it.
+int raisr_hip_stream_set_model_blob_device(raisr_hip_stream* s, int pass_index, const void* device_blob, size_t bytes, void* stream)
+{
+    if (!s) return RAISR_HIP_EINVAL;
+    for (raisr_hip_ctx* c : s->lanes) {
+        const int rc = raisr_hip_set_model_blob_device(c, pass_index, device_blob, bytes, stream);
+        if (rc != RAISR_HIP_OK) return rc;
+    }
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_stream_set_fast(raisr_hip_stream* s, int level)
+{
+    if (!s) return RAISR_HIP_EINVAL;
+    for (size_t i = 0; i < s->lanes.size(); i++)
+        if (s->busy[i]) return RAISR_HIP_ESTATE;
+    for (raisr_hip_ctx* c : s->lanes) {
+        const int rc = raisr_hip_set_fast(c, level);
+        if (rc != RAISR_HIP_OK) return rc;
+    }
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_stream_configure(raisr_hip_stream* s, const raisr_hip_config* cfg)
 {
     if (!s || !cfg) return RAISR_HIP_EINVAL;

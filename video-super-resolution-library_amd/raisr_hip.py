@@ -108,6 +108,8 @@ def lib():
         L.raisr_hip_stream_destroy.argtypes = [ctypes.c_void_p]
         L.raisr_hip_stream_destroy.restype = None
         L.raisr_hip_stream_depth.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_stream_set_model_blob_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.raisr_hip_stream_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_stream_set_model.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_stream_configure.argtypes = [ctypes.c_void_p, ctypes.POINTER(RaisrHipConfig)]
@@ -442,12 +444,18 @@ class RaisrStream:
     """depth frames in flight through one GPU: submit() enqueues, collect() waits for the oldest frame."""
 
     def __init__(self, device, folder, in_w, in_h, out_w, out_h, bits=8, full_range=False, passes=1, mode=1,
-                 hash_variant=HASH_AVX512, blending=BLEND_COUNT, chroma=None, depth=4, tie=TIE_HALF_UP):
+                 hash_variant=HASH_AVX512, blending=BLEND_COUNT, chroma=None, depth=4, tie=TIE_HALF_UP, blobs=None):
+        """`blobs`: per-pass (device pointer, bytes) of packed model blobs already in device memory (the multi-GPU start-up:
+        rank 0 packs, RCCL broadcasts); otherwise the model is read from `folder`."""
         self._h = ctypes.c_void_p()
         _check(lib().raisr_hip_stream_create(ctypes.byref(self._h), device, depth), "raisr_hip_stream_create")
         self.depth = depth
         try:
             for p in range(passes):
+                if blobs is not None:
+                    _check(lib().raisr_hip_stream_set_model_blob_device(self._h, p, blobs[p][0], blobs[p][1], None),
+                           "raisr_hip_stream_set_model_blob_device")
+                    continue
                 bank, qstr, qcoh, qa = read_model_folder(folder, bits, p + 1)
                 bank = np.ascontiguousarray(bank, np.float32)
                 qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
@@ -467,6 +475,9 @@ class RaisrStream:
             self.close()
             raise
         self.chroma = chroma            # (in_w, in_h, out_w, out_h) of each chroma plane, or None
+
+    def set_fast(self, level):
+        _check(lib().raisr_hip_stream_set_fast(self._h, int(level)), "raisr_hip_stream_set_fast")
 
     def submit(self, y, u, v, oy, ou, ov):
         def pp(a):
