@@ -24,6 +24,8 @@ and, at N = 1 (outside the timed region of `value`, never mixed into it):
   parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR
   fast_mode    -- the opt-in, NOT bit-exact matrix-core filter stage (raisr_hip_set_fast(2)): the same loop, with its
                   distance from the oracle beside it.  Never the headline.
+At N > 1 the line carries `stream` only: every rank streaming host-resident frames through its pinned ring at the same
+time (PCIe / host-memory contention next to the HBM-resident headline).
 """
 import argparse
 import hashlib
@@ -499,6 +501,21 @@ def main():
         if timing and rank == 0:
             iso = isolated_kernel_ms(lanes, d_in, d_out, wl, torch)
 
+    # N > 1: the headline keeps frames resident in HBM (weak scaling of the kernels); beside it, every rank also streams
+    # host-resident frames through its pinned ring AT THE SAME TIME, so the scaling record contains PCIe / host-memory contention
+    multi_stream = None
+    if world > 1 and not args.stream and not args.no_extras and hasattr(R, "RaisrStream"):
+        try:
+            fence()
+            res = stream_leg(R, wl, gpu, args.extra_frames, blobs=blobs)
+            dts = sharding.max_over_ranks(args.extra_frames / res["fps"], dev, dist if use_dist else None)
+            multi_stream = {"value": round(wl.out_w * wl.out_h * args.extra_frames * world / dts / 1e6, 2), "unit": "MP/s",
+                            "fps": round(args.extra_frames * world / dts, 2), "frames_per_rank": args.extra_frames,
+                            "what": "host planes -> host planes on every rank concurrently (pinned ring, PCIe inclusive), max over ranks"}
+        except Exception as e:  # all ranks take the same path; a failure here must not lose the headline
+            multi_stream = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            sharding.max_over_ranks(0.0, dev, dist if use_dist else None)
+
     if rank == 0:
         mp_s = wl.out_w * wl.out_h * frames_total / dt / 1e6
         # roofline of the dominant kernel: algorithmic bytes per launch / mean launch time
@@ -596,6 +613,8 @@ def main():
             "cpu_baseline": cpu,
         }
         line.update(extras)
+        if multi_stream is not None:
+            line["stream"] = multi_stream
         import ctypes
         ctypes.CDLL(None).fflush(None)                       # nothing buffered by the C runtime may follow the JSON line
         print(json.dumps(line), flush=True)

@@ -71,6 +71,20 @@ def test_bench_two_ranks_on_one_gpu_plumbing():
     assert j["value"] > 0 and abs(j["value"] - j["config"]["fps"] * 3840 * 2160 / 1e6) < 1.0
 
 
+def test_bench_two_ranks_report_a_streamed_leg():
+    """N > 1 without --no-extras: beside the HBM-resident headline every rank streams host frames through its ring at the same
+    time, so a scaling record sees PCIe / host-memory contention (SURVEY s8e's scaling risks)."""
+    env = dict(os.environ, RAISR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29545", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "8", "--no-cpu-baseline", "--extra-frames", "12"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _one_json_line(out.stdout)
+    assert j["n_gpus"] == 2 and j["stream"]["value"] > 0 and j["stream"]["frames_per_rank"] == 12
+    assert "c3_2pass" not in j                      # the single-GPU side legs stay single-GPU
+
+
 def test_bench_gpus_flag_is_honoured_or_fails_loudly():
     """`python bench.py --gpus 2` (no torchrun around it) must start two ranks itself; on a box with fewer than two
     devices it has to fail -- never print a line for a world size it did not run."""
