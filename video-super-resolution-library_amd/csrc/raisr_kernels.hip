@@ -2313,14 +2313,13 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             }
-            if (c->fast) {
+            if (c->fast && c->model[pass].bank_mfma) {             // the panels are allocated by configure / set_fast (errors reported there)
                 ModelDev& m = c->model[pass];
-                if (!m.bank_mfma && hipMalloc((void**)&m.bank_mfma, kMfBankHalfs * sizeof(_Float16)) != hipSuccess) m.bank_mfma = nullptr;
-                if (m.bank_mfma && !m.bank_mfma_valid) {
+                if (!m.bank_mfma_valid) {
                     hipLaunchKernelGGL(k_build_mfma_bank, dim3((unsigned)((kMfBankHalfs + 255) / 256)), dim3(256), 0, s, P.bank, m.bank_mfma);
                     m.bank_mfma_valid = true;
                 }
-                if (m.bank_mfma) {                                 // (allocation failure surfaces as the missing launch: checked by the caller's hipGetLastError path)
+                {
                     dim3 gm((P.c_final - kMargin + kMfW - 1) / kMfW, (H - 2 * kMargin + kMfH - 1) / kMfH);
                     timer_begin(c, "k_filter_mfma", s, slot);
                     static const int mpart = getenv("RAISR_HIP_MF_PART") ? atoi(getenv("RAISR_HIP_MF_PART")) : 0;
@@ -2758,11 +2757,29 @@ static bool fast_mode_supported(const raisr_hip_config* cfg)
     return cfg->use_pixel_type && cfg->bits <= 10 && cfg->hash_variant != RAISR_HIP_HASH_FP16;
 }
 
+// B panels of k_filter_mfma for every pass in use (590 KB each); filled on the stream by the first frame that needs them
+static int alloc_fast_banks(raisr_hip_ctx* c, int passes)
+{
+    for (int p = 0; p < passes; p++) {
+        ModelDev& m = c->model[p];
+        if (!m.bank_mfma) {
+            if (hipMalloc((void**)&m.bank_mfma, kMfBankHalfs * sizeof(_Float16)) != hipSuccess) { m.bank_mfma = nullptr; return fail(RAISR_HIP_ENOMEM, "fast mode: filter panel alloc"); }
+            m.bank_mfma_valid = false;
+        }
+    }
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_set_fast(raisr_hip_ctx* c, int on)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null argument");
     if (on && c->configured && !fast_mode_supported(&c->cfg))
         return fail(RAISR_HIP_EINVAL, "fast mode (matrix-core filter stage) supports ratio 2, 8/10-bit content and the fp32 flavours only");
+    if (on > 0 && c->configured) {
+        HIP_TRY(hipSetDevice(c->device));
+        const int rc = alloc_fast_banks(c, c->cfg.passes);
+        if (rc) return rc;
+    }
     c->fast = on < 0 ? 0 : (on > 2 ? 2 : on);
     return RAISR_HIP_OK;
 }
@@ -2839,6 +2856,10 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
             if (hipMalloc((void**)&c->d_mid, n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
             HIP_TRY(hipMemset(c->d_mid, 0, n * bps));
         }
+    }
+    if (c->fast) {
+        const int rc = alloc_fast_banks(c, cfg->passes);
+        if (rc) { free_scratch(c); return rc; }
     }
     c->blending = cfg->blending;
     c->configured = true;
