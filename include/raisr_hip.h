@@ -168,8 +168,15 @@ int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
  * through raisr_hip_host_register) frame n+1's upload and frame n-1's download overlap frame n's kernels; pageable planes
  * work too, without the overlap (the runtime stages them on the calling thread).  This is the batch entry beside the
  * synchronous RNLProcess (Library/Raisr.cpp:1294-1397), which keeps its one-frame contract.  One thread drives a stream. */
+/* Advanced (what the stream ring is built from): run a context's host-plane entry points on caller-owned streams -- kernels on
+ * `compute`, every upload on `upload`, every download on `download` (hipStream_t, all three or none; NULLs restore the context's
+ * own streams).  Several contexts sharing the same three streams form a stage-ordered pipeline: uploads, kernels and downloads
+ * of consecutive frames each run back to back, in frame order, with device-side events between the stages.
+ * raisr_hip_synchronize() then waits for that context's last frame only.  The streams must outlive their use by the context. */
+int  raisr_hip_use_streams(raisr_hip_ctx *ctx, void *compute, void *upload, void *download);
+
 typedef struct raisr_hip_stream raisr_hip_stream;
-int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..16 */
+int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..16; at most 4 lanes are built (one stream each) */
 void raisr_hip_stream_destroy(raisr_hip_stream *s);
 int  raisr_hip_stream_depth(const raisr_hip_stream *s);
 int  raisr_hip_stream_set_model(raisr_hip_stream *s, int pass_index, const float *bank, int hashkeys, int pixel_types,

@@ -20,13 +20,28 @@ struct raisr_hip_stream {
     std::vector<char> busy;          // lane has a submitted, not yet collected frame
     size_t head = 0, tail = 0;       // next lane to submit to / to collect from
     bool configured = false;
+    // One stream per lane, at most kMaxLanes = 4 of them (the runtime has four hardware queues; more streams alias onto shared
+    // queues): a lane runs whole frames -- uploads, Y kernels, the two cheap chroma upscales, one download -- on its stream.
+    // Measured on the way here (scripts/stream_probe.py, stream_trace.sh, copy_engine_probe.hip; 1080p -> 4K yuv420p, PCIe
+    // ceiling of the box 4.19 k fps): this layout 3.9-4.2 k fps in 18 of 18 runs; two streams per lane (chroma on its own,
+    // round 2a) anywhere between 2.6 k and 4.0 k; six lanes on four streams 2.7 k; uploads on a shared upload stream make the
+    // runtime hand the downloads to a copy KERNEL instead of the DMA engine (takes CUs from the next frame's kernels): 2.0-3.0 k.
+    hipStream_t comp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nstreams = 0;
 };
+
+static void destroy_streams(raisr_hip_stream* s)
+{
+    (void)hipSetDevice(s->device);
+    for (hipStream_t& c : s->comp) if (c) (void)hipStreamDestroy(c);
+}
 
 extern "C" {
 
 int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
 {
     if (!out || depth < 1 || depth > 16) return RAISR_HIP_EINVAL;
+    if (depth > 4) depth = 4;                                           // see raisr_hip_stream::comp; raisr_hip_stream_depth() reports what was built
     raisr_hip_stream* s = new raisr_hip_stream();
     s->device = device_index;
     for (int i = 0; i < depth; i++) {
@@ -40,6 +55,22 @@ int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
         s->lanes.push_back(c);
     }
     s->busy.assign((size_t)depth, 0);
+    const char* legacy = getenv("RAISR_HIP_RING_LANE_STREAMS");         // A/B switch: 1 = every lane on its own streams (round-2a behaviour)
+    if (!(legacy && atoi(legacy) != 0)) {
+        s->nstreams = depth;
+        bool ok = hipSetDevice(device_index) == hipSuccess;
+        for (int i = 0; ok && i < s->nstreams; i++) ok = hipStreamCreateWithFlags(&s->comp[i], hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < depth; i++) {
+            hipStream_t c = s->comp[i % s->nstreams];
+            ok = raisr_hip_use_streams(s->lanes[(size_t)i], c, c, c) == RAISR_HIP_OK;
+        }
+        if (!ok) {
+            for (raisr_hip_ctx* p : s->lanes) raisr_hip_destroy(p);
+            destroy_streams(s);
+            delete s;
+            return RAISR_HIP_ERUNTIME;
+        }
+    }
     *out = s;
     return RAISR_HIP_OK;
 }
@@ -47,7 +78,8 @@ int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
 void raisr_hip_stream_destroy(raisr_hip_stream* s)
 {
     if (!s) return;
-    for (raisr_hip_ctx* c : s->lanes) { (void)raisr_hip_synchronize(c); raisr_hip_destroy(c); }
+    for (raisr_hip_ctx* c : s->lanes) { (void)raisr_hip_synchronize(c); (void)raisr_hip_use_streams(c, nullptr, nullptr, nullptr); raisr_hip_destroy(c); }
+    destroy_streams(s);
     delete s;
 }
 

@@ -449,7 +449,7 @@ class RaisrStream:
         rank 0 packs, RCCL broadcasts); otherwise the model is read from `folder`."""
         self._h = ctypes.c_void_p()
         _check(lib().raisr_hip_stream_create(ctypes.byref(self._h), device, depth), "raisr_hip_stream_create")
-        self.depth = depth
+        self.depth = int(lib().raisr_hip_stream_depth(self._h))      # the library builds at most 4 lanes
         try:
             for p in range(passes):
                 if blobs is not None:
