@@ -123,3 +123,34 @@ def test_stream_ring_from_a_device_blob_and_fast_passthrough():
         assert np.array_equal(outs[0], oracle_y(ys[0], case))
     finally:
         st.close()
+
+
+def test_context_on_caller_owned_streams():
+    """raisr_hip_use_streams: host-plane frames on caller-owned streams (what the ring is built from) -- one stream for all three
+    roles, and separate upload / compute / download streams with device-side events between the stages; same bits; restorable."""
+    import torch
+    import raisr_hip as R
+    import synth
+    fold = "filters_2x/filters_highres"
+    w, h = 200, 120
+    case = ("x", fold, (2, 1), 8, 2, 1, 2, False)
+    y = synth.natural_y(w, h, 8, seed=31)
+    u = synth.random_y(w // 2, h // 2, 8, seed=32)
+    ref = oracle_y(y, case)
+    s = [torch.cuda.Stream() for _ in range(3)]
+    dev = R.RaisrDevice(0)
+    try:
+        dev.set_model_from_folder(folder(fold), 8, 2)
+        dev.configure(w, h, 2 * w, 2 * h, bits=8, passes=2, mode=1, hash_variant=2)
+        for streams in ((s[0], s[0], s[0]), (s[0], s[1], s[2]), None):
+            if streams:
+                dev.use_streams(*[x.cuda_stream for x in streams])
+            else:
+                dev.use_streams()
+            oy = np.zeros((2 * h, 2 * w), np.uint8); ou = np.zeros((h, w), np.uint8); ov = np.zeros((h, w), np.uint8)
+            dev.process_host(y, oy, u, ou, u, ov)
+            assert np.array_equal(oy, ref) and np.array_equal(ou, ov) and ou.any()
+        with pytest.raises(RuntimeError):
+            dev.use_streams(s[0].cuda_stream, None, None)
+    finally:
+        dev.close()

@@ -127,6 +127,7 @@ def lib():
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_use_streams.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_broadcast_model_blob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_get_fast.argtypes = [ctypes.c_void_p]
         L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -358,6 +359,10 @@ class RaisrDevice:
         _check(lib().raisr_hip_debug_approx_hash(self._h, pass_index, flavour, abd.ctypes.data, n, bucket.ctypes.data, cert.ctypes.data,
                                                  ctypes.byref(eps)), "debug_approx_hash")
         return bucket, cert.astype(bool), float(eps.value)
+
+    def use_streams(self, compute=None, upload=None, download=None):
+        """Run the host-plane entry points on caller-owned hipStream_t handles (all three or none; None restores the context's own)."""
+        _check(lib().raisr_hip_use_streams(self._h, compute, upload, download), "raisr_hip_use_streams")
 
     def set_fast(self, on=1):
         """NON-bit-exact fast mode. 1: exact buckets, filter stage on the matrix cores (binary16 coefficients);
