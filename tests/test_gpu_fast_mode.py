@@ -155,3 +155,31 @@ def test_fast_mode_through_the_plugin_api_is_an_environment_switch(monkeypatch):
     monkeypatch.delenv("RAISR_HIP_FAST")
     oy, _, _ = R.upscale_frame_host(y, c, c, folder("filters_2x/filters_highres"), ratio=2.0, bits=8, asm_type=R.AVX512)
     assert np.array_equal(oy, ref)
+
+
+def _geometry_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        w = int(rng.integers(7, 300)); h = int(rng.integers(7, 200))
+        bits = 10 if rng.random() < 0.3 else 8
+        passes = int(rng.choice([1, 2])); mode = int(rng.choice([1, 2])) if passes == 2 else 1
+        out.append((w, h, bits, int(rng.choice([1, 2])), passes, mode, bool(rng.random() < 0.3), int(rng.choice([1, 2])), int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("g", _geometry_cases(32, 424242), ids=lambda g: f"{g[0]}x{g[1]}_{g[2]}b_a{g[3]}_p{g[4]}m{g[5]}_l{g[7]}")
+def test_fast_mode_random_geometries(g):
+    """Areas cut by the frame edge, frames smaller than one 128 x 32 area or than the filter margin, both bit depths, passes and
+    levels: the output stays within the mode's budget of the oracle and the border policy holds."""
+    import synth
+    w, h, bits, asm, passes, mode, full, level, seed = g
+    case = ("x", "filters_2x/filters_highres", (2, 1), bits, passes, mode, asm, full)
+    y = synth.natural_y(w, h, bits, seed=seed)
+    ref = oracle_y(y, case)
+    out, _ = _run(case, y, level)
+    assert out.shape == ref.shape
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[-1], ref[-1]) and np.array_equal(out[:, 0], ref[:, 0]) and np.array_equal(out[:, -1], ref[:, -1])
+    d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+    lsb = 1 << (bits - 8)
+    assert _psnr(out, ref, bits) > 44.0 and (d > 4 * lsb).mean() < 0.01, (g, _psnr(out, ref, bits), float((d > 4 * lsb).mean()), int(d.max()))
