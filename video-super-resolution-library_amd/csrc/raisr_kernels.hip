@@ -2579,6 +2579,7 @@ static int create_impl(raisr_hip_ctx* c)
     for (int i = 0; i < 1024; i++) { t16[i] = X86_RCPPH_T[i]; t16[1024 + i] = X86_RSQRTPH_T0[i]; t16[2048 + i] = X86_RSQRTPH_T1[i]; }
     HIP_TRY(hipMalloc((void**)&c->d_tab16, t16.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(c->d_tab16, t16.data(), t16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());           // (null-stream copies are not ordered with the non-blocking streams the kernels use)
     {   // un-normalised Gaussian in binary16, (fp16)literal (Raisr_globals.h:267-278)
         for (int i = 0; i < 11; i++)
             for (int k = 0; k < 11; k++) {
@@ -2681,7 +2682,7 @@ static int compute_zero_buckets(raisr_hip_ctx* c, int pass_index)
     if (hipMalloc((void**)&d_out, 2) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
     int rc = RAISR_HIP_OK;
     uint8_t h[2] = {0, 0};
-    if (hipMemset(d_in, 0, 3 * sizeof(float)) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemset");
+    if (hipMemsetAsync(d_in, 0, 3 * sizeof(float), c->stream) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemset");   // stream-ordered before k_debug_hash
     PassParams P = make_pass(c, pass_index, 0, 0);
     for (int legacy = 0; legacy < 2 && !rc; legacy++) {
         hipLaunchKernelGGL(k_debug_hash, dim3(1), dim3(256), 0, c->stream, d_in, 1u, P, legacy, d_out + legacy);
@@ -2758,6 +2759,7 @@ int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int
     if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
     if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
     HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());           // frames run on non-blocking streams, which nothing orders after a null-stream copy
     m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true; m.bank_mfma_valid = false;
     return compute_zero_buckets(c, pass_index);
 }
@@ -2856,21 +2858,26 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
             free_scratch(c);
             return fail(RAISR_HIP_ENOMEM, "worklist alloc");
         }
-        HIP_TRY(hipMemset(c->fix.counters, 0, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(c->fix.counters, 0, 2 * sizeof(unsigned), c->stream));
     }
     if (cfg->passes == 2) {
         // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
-        HIP_TRY(hipMemset(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * bps));
+        HIP_TRY(hipMemsetAsync(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * bps, c->stream));
         if (c->passW[0] != c->passW[1] || c->passH[0] != c->passH[1]) {
             const size_t n = (size_t)c->passW[0] * c->passH[0];
             if (hipMalloc((void**)&c->d_mid, n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
-            HIP_TRY(hipMemset(c->d_mid, 0, n * bps));
+            HIP_TRY(hipMemsetAsync(c->d_mid, 0, n * bps, c->stream));
         }
     }
     if (c->fast) {
         const int rc = alloc_fast_banks(c, cfg->passes);
         if (rc) { free_scratch(c); return rc; }
     }
+    // The clears above must have LANDED before any frame runs: frames may be enqueued on other (non-blocking) streams -- the
+    // ring's, a caller's -- which are not ordered after this one, and a null-stream hipMemset is not ordered with them either
+    // (a clear overtaking a frame's pass-1 output showed up as a 1-in-5 mismatch of a small 2-pass test).
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
     c->blending = cfg->blending;
     c->configured = true;
     return RAISR_HIP_OK;
@@ -3207,7 +3214,7 @@ int raisr_hip_debug_certify(raisr_hip_ctx* c, int collect, int check)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (collect && !c->d_cert_stats) HIP_TRY(hipMalloc((void**)&c->d_cert_stats, 3 * sizeof(unsigned)));
-    if (c->d_cert_stats) HIP_TRY(hipMemset(c->d_cert_stats, 0, 3 * sizeof(unsigned)));
+    if (c->d_cert_stats) { HIP_TRY(hipMemsetAsync(c->d_cert_stats, 0, 3 * sizeof(unsigned), c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     if (!collect && c->d_cert_stats) { (void)hipFree(c->d_cert_stats); c->d_cert_stats = nullptr; }
     c->cert_check = check != 0;
     return RAISR_HIP_OK;
@@ -3240,6 +3247,7 @@ int raisr_hip_debug_approx_hash(raisr_hip_ctx* c, int pass_index, int hash_flavo
     int rc = RAISR_HIP_OK;
     PassParams P = make_pass(c, pass_index, 0, 0);
     if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipDeviceSynchronize");
     if (!rc) {
         hipLaunchKernelGGL(k_debug_approx_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P, c->sep,
                            hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out, d_out + n);
@@ -3267,6 +3275,7 @@ int raisr_hip_debug_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, con
     int rc = RAISR_HIP_OK;
     PassParams P = make_pass(c, pass_index, 0, 0);
     if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipDeviceSynchronize");
     if (!rc) {
         hipLaunchKernelGGL(k_debug_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P,
                            hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out);
