@@ -170,3 +170,29 @@ def test_certified_buckets_hold_on_the_whole_error_box(flavour):
         bad_total += int(bad.sum())
         assert not bad.any(), (sg.tolist(), int(bad.sum()), abd[sel][bad][:3].tolist(), X[bad][:3].tolist(), bucket[sel][bad][:3].tolist(), hx[bad][:3].tolist())
     assert bad_total == 0
+
+
+def test_zero_tensor_bucket_is_stable_across_context_lifetimes():
+    """The bucket of the all-zero tensor is computed on the device when a model is set (k_debug_hash on the context stream).  Its
+    input used to be cleared on the null stream, which nothing orders with a non-blocking stream: when the kernel won the race
+    the bucket came out of stale memory and every flat-window pixel took a wrong filter (seen once as 16 k mismatches on a 1-px
+    checkerboard, whose central differences all vanish).  Many create / set model / first frame cycles, flat-gradient content."""
+    import raisr_hip as R
+    import synth
+    case = ("2x_10b_2p_m2", "filters_2x/filters_denoise", (2, 1), 10, 2, 2, 2, False)
+    frames = [synth.checker_y(96, 64, 10), synth.constant_y(96, 64, 10)]
+    refs = [oracle_y(y, case) for y in frames]
+    junk = []
+    for it in range(24):
+        import torch
+        junk.append(torch.full((1 + it,), float("nan"), device="cuda"))      # dirty a few small device allocations in between
+        y, ref = frames[it % 2], refs[it % 2]
+        dev = R.RaisrDevice(0)
+        try:
+            dev.set_model_from_folder(folder(case[1]), 10, 2)
+            dev.configure(96, 64, 192, 128, bits=10, passes=2, mode=2, hash_variant=2)
+            out = np.zeros((128, 192), np.uint16)
+            dev.process_host(y, out)
+        finally:
+            dev.close()
+        assert np.array_equal(out, ref), it
