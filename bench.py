@@ -207,6 +207,33 @@ def measured_traffic(kernel):
     return None, "no PMC pass recorded for these kernel sources (run scripts/profile_gpu.sh)"
 
 
+def bind_to_gpu_numa_node(torch, gpu):
+    """N > 1: run this rank on the CPUs of the NUMA node its GPU hangs off, so that the page-locked frame planes of the streamed leg
+    (first touch) and the threads that fill them are local to the PCIe root (NUMA placement of pinned buffers).
+    Returns a short description for the JSON line; never fatal."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(32)
+        if hip.hipDeviceGetPCIBusId(buf, 32, gpu) != 0:
+            return "unknown (no PCI bus id)"
+        bdf = buf.value.decode()
+        node = int(open(f"/sys/bus/pci/devices/{bdf.lower()}/numa_node").read())
+        if node < 0:
+            return "single node"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return f"node {node} (not in this process's CPU set: unbound)"
+        os.sched_setaffinity(0, allowed)
+        return f"node {node} ({len(allowed)} CPUs)"
+    except Exception as e:  # placement is an optimisation, never a reason to lose the line
+        return f"unbound ({type(e).__name__})"
+
+
 def respawn_ranks(args):
     """--gpus N > 1 outside torchrun: start the N ranks ourselves, exactly as the driver would."""
     s = socket.socket()
@@ -442,6 +469,7 @@ def main():
     # (ranks beyond the visible devices wrap around only for the 2-ranks-on-1-GPU plumbing test, which swaps RCCL for
     #  gloo via RAISR_BENCH_BACKEND -- RCCL refuses two ranks on one device)
     gpu = local_rank % ndev
+    numa = bind_to_gpu_numa_node(torch, gpu) if world > 1 and os.environ.get("RAISR_BENCH_NUMA", "1") != "0" else None
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     # launched by torch.distributed.run (RANK set) -> always go through RCCL, even with one rank, so the
@@ -606,7 +634,7 @@ def main():
                        "frame_kind": args.frame_kind, "mode": "exact" if not fast_level else f"fast-{fast_level} (NOT bit-exact: RAISR_HIP_FAST is set)",
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "timed_region_s": round(dt, 3),
-                       "parallelism": f"frame-shard x{world}"},
+                       "parallelism": f"frame-shard x{world}"} | ({"numa_rank0": numa} if numa else {}),
             "kernels_avg_ms": kernels_ms,
             "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()},
             "roofline": roofline,
