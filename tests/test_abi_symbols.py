@@ -71,6 +71,10 @@ int main(void) {
     /* a folder without a config file must be refused before any GPU work (Raisr.cpp:1531-1539) */
     if (RNLHandler_Init("/nonexistent-model-folder", 2.0f, 8, VideoRange, 20, AVX512, 1, 1) != RNLErrorBadParameter) return 6;
     if (RNLHandler_Process(&v, &v, &v, &v, &v, &v, CountOfBitsChanged) != RNLErrorBadParameter) return 7;
+    /* the entry points added in round 2 reject null handles with an error code (no GPU work before the check) */
+    if (raisr_hip_set_fast(NULL, 1) == RAISR_HIP_OK || raisr_hip_use_streams(NULL, NULL, NULL, NULL) == RAISR_HIP_OK) return 8;
+    if (raisr_hip_broadcast_model_blob(NULL, 0, NULL, 0, NULL) == RAISR_HIP_OK || raisr_hip_stream_set_fast(NULL, 1) == RAISR_HIP_OK) return 9;
+    if (raisr_hip_stream_depth(NULL) != 0 || raisr_hip_get_fast(NULL) != 0) return 10;
     puts("c-client-ok");
     return 0;
 }
