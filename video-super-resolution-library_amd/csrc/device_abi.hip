@@ -1,0 +1,1384 @@
+// device_abi.hip -- the C ABI of include/raisr_hip.h (contexts, models, geometry, frame entry points, stream plumbing) and the
+// ONE translation unit the gfx950 kernels are compiled in.  The kernels live in the kernels_*.h headers next to this file:
+//
+//   kernels_resize.h        k_resize / k_resize2x / k_copy   cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958)  in -> LR
+//   kernels_hash.h          hash_px_*, hash_phase, k_hash    the reference's tensor + hash (Raisr_AVX512.cpp:69-131,175-258;
+//                                                            tail columns also Raisr_AVX256.cpp:393-472)
+//   kernels_hash_certify.h  approx_hash, hash_phase_ac       certified hashing: approximate tensor, rigorous bounds, exact fallback
+//   kernels_filter.h        filter_phase, k_filter,          hash-indexed 121-tap filter + accept test (Raisr_AVX512.cpp:134-149,
+//                           k_hashfilter, k_hashfilter_ac    Raisr.cpp:1196-1200); k_hashfilter_ac = PRODUCTION kernel of the fp32 numerics:
+//                                                            per 64 x 16 tile, hash stage and filter stage sharing one LR window in LDS
+//   kernels_fp16.h          k_hashfilter16, k_blend16, ...   the AVX512-FP16 numerics in binary16 (Raisr_AVX512FP16.cpp)
+//   kernels_blend.h         k_blend, k_blend_rand            census-transform blend, clamp, narrow, borders (Raisr_AVX256.cpp:68-166,
+//                                                            Raisr.cpp:999-1028,1252-1265)
+//   kernels_split.h         k_hash_ac, k_fix_*, k_filter_lds16   selectable alternative: un-fused pipeline, filter bank in LDS (RAISR_HIP_SPLIT=1)
+//   kernels_fast.h          k_filter_mfma                    opt-in, NOT bit-exact: filter stage on the matrix cores
+//
+// Pipeline per RAISR pass (whole-frame semantics of the reference's processSegment(), Library/Raisr.cpp:890-1289, run with
+// threadcount=1):  k_resize -> k_hashfilter_ac -> k_blend.
+//
+// Numeric contract: every floating-point operation in the kernels maps to exactly one IEEE-754 binary32 (binary16) operation of
+// the cited reference lines ("strict source" semantics).  This file MUST be built with -ffp-contract=off and without fast-math;
+// FMAs appear only where the reference has an explicit fmadd intrinsic.
+//
+// Design notes (MI355X): the work is fp32-VALU bound (~1.3 kFLOP per output pixel per pass against ~1.25 compulsory HBM bytes)
+// and, in the filter stage, vector-L1 bound (512 B of coefficients per pixel), so the kernels are organised around
+// VALU/LDS/L1 efficiency.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/raisr_hip.h"
+#include "x86_approx_tables.h"
+#include "x86_approx_dev.h"
+#include "x86_fp16_tables.h"
+
+#if defined(__FAST_MATH__)
+#error "device_abi.hip must be compiled without fast-math"
+#endif
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+
+namespace {
+
+#include "kernels_common.h"          // PassParams, xcd_tile, stage_tile
+#include "kernels_resize.h"          // k_resize, k_resize2x, k_copy
+#include "kernels_hash.h"            // hash_px_*, hash_phase, k_hash
+#include "kernels_hash_certify.h"    // approx_hash, tensor_ac, hash_phase_ac
+#include "kernels_fp16.h"            // binary16 pipeline: k_hashfilter16, k_hash16, k_filter16, k_blend16
+#include "kernels_filter.h"          // filter_phase, k_filter, k_hashfilter, k_hashfilter_ac
+#include "kernels_split.h"           // k_hash_ac, k_fix_*, k_filter_lds16
+#include "kernels_fast.h"            // k_filter_mfma
+#include "kernels_blend.h"           // k_blend, k_blend_rand
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    g_err = what;
+    if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) return fail(RAISR_HIP_ERUNTIME, #expr, _e);      \
+    } while (0)
+
+struct BlobHeader {
+    uint32_t magic;
+    int32_t hashkeys, pixel_types, quant_angle;
+    float qangle, qstr[2], qcoh[2];
+    uint16_t qangle16, qstr16[2], qcoh16[2];   // binary16 flavours for the AVX512-FP16 pipeline
+    uint16_t pad16;
+    uint32_t pad[4];
+};
+static_assert(sizeof(BlobHeader) == kBlobHeader, "blob header size");
+constexpr uint32_t kBlobMagic = 0x52534152u;   // "RASR"
+
+// blob = header | fp32 bank [rows][128] | fp16 bank [rows][4][16] half2
+inline size_t blob_f32_bytes(int rows) { return (size_t)rows * kTapsPad * sizeof(float); }
+inline size_t blob_f16_bytes(int rows) { return (size_t)rows * 64 * sizeof(uint32_t); }
+
+struct ModelDev {
+    void* blob = nullptr;
+    size_t bytes = 0;
+    BlobHeader h{};
+    bool valid = false;
+    int zero_bucket[2] = {0, 0};           // bucket of the all-zero tensor, AVX-512 / AVX2 flavour (from the device hash code)
+    _Float16* bank_mfma = nullptr;         // fast mode: binary16 B panels of k_filter_mfma, built on first use
+    bool bank_mfma_valid = false;
+};
+
+struct KernelTimer {
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;                 // recs[i] uses pool[2i], pool[2i+1]
+    std::vector<hipEvent_t> pool;          // created once at enable time, outside any timed region
+    std::vector<std::string> names;
+    bool enabled = false;
+    size_t cap = 4096;                     // launches recorded per enable; later launches run untimed
+};
+
+int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// Gaussian weights: gGaussian2D{8,10,16}bit (Raisr_globals.h:208-264) = (float)((double)NF * literal);
+// the literal table is symmetric, Q is its upper-left quadrant.
+const double kGaussQ[6][6] = {
+    {7.76554e-05, 0.000239195, 0.0005738, 0.001072, 0.00155975, 0.00176743},
+    {0.000239195, 0.000736774, 0.00176743, 0.00330199, 0.00480437, 0.00544406},
+    {0.0005738, 0.00176743, 0.00423984, 0.00792107, 0.0115251, 0.0130596},
+    {0.001072, 0.00330199, 0.00792107, 0.0147985, 0.0215317, 0.0243986},
+    {0.00155975, 0.00480437, 0.0115251, 0.0215317, 0.0313284, 0.0354998},
+    {0.00176743, 0.00544406, 0.0130596, 0.0243986, 0.0354998, 0.0402265},
+};
+
+GaussW make_gauss(int bits)
+{
+    GaussW g{};
+    const float maxv = bits == 8 ? 255.0f : (bits == 10 ? 1023.0f : 65535.0f);
+    volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
+    for (int i = 0; i < 11; i++)
+        for (int k = 0; k < 11; k++) {
+            const int qi = i < 6 ? i : 10 - i, qk = k < 6 ? k : 10 - k;
+            g.wT[k][i] = (float)((double)nf * kGaussQ[qi][qk]);
+        }
+    return g;
+}
+
+// Separable weights and error constants of the certified hash stage (see the comment above approx_hash).
+// us_i = sqrt(NF * literal_ii): the literal table is the outer product of a 1-D Gaussian up to its 6-digit truncation.
+// eps_w is measured on the very fp32 constants the two paths use, so it is a bound, not an estimate.
+SepW make_sep(const GaussW& g)
+{
+    SepW S{};
+    for (int i = 0; i < 11; i++) S.us[i] = (float)sqrt((double)g.wT[i][i]);
+    double eps_w = 0.0;
+    for (int i = 0; i < 11; i++)
+        for (int k = 0; k < 11; k++) {
+            const double r = (double)S.us[i] * (double)S.us[k] / (double)g.wT[k][i] - 1.0;
+            if (fabs(r) > eps_w) eps_w = fabs(r);
+        }
+    const double u = 5.9604644775390625e-8;                     // 2^-24
+    const double eps = 1.05 * (eps_w + 48.0 * u);
+    const double E[2] = {1.0e-4, 6.5e-4};                       // sup |sqrt14(x)/sqrt(x) - 1|: VRCP14(VRSQRT14), RCPPS(RSQRTPS)
+    S.es1 = (float)(1.42 * eps);
+    S.es2 = (float)(2e-7 + eps * eps);
+    S.eEL = (float)(0.5 * eps + 6.0 * u);
+    S.eEb = (float)(0.5 * eps);
+    for (int f = 0; f < 2; f++) { S.e105[f] = (float)(1.05 * E[f]); S.e24[f] = (float)(2.4 * E[f]); }
+    return S;
+}
+
+// Column plan of the reference's chunk driver (Raisr.cpp:1065-1066,1246-1250).
+void column_plan(int W, int hash_variant, PassParams& P)
+{
+    const int unroll = hash_variant == RAISR_HIP_HASH_AVX512 ? 16 : (hash_variant == RAISR_HIP_HASH_FP16 ? 32 : 8);
+    int loopItr = unroll, c = kMargin;
+    P.a_begin = P.a_end = P.b_begin = P.b_end = kMargin;
+    bool a_any = false, b_any = false;
+    while (c + loopItr <= W - kMargin) {
+        if (loopItr >= 16) { if (!a_any) { P.a_begin = c; a_any = true; } P.a_end = c + loopItr; }
+        else { if (!b_any) { P.b_begin = c; b_any = true; } P.b_end = c + 8; }
+        if (loopItr > 8 && c + 2 * unroll > W - kMargin) loopItr = 8;
+        c += loopItr;
+    }
+    P.c_final = a_any || b_any ? (b_any ? P.b_end : P.a_end) : kMargin;
+    if (a_any && b_any && P.a_end > P.b_end) P.c_final = P.a_end;
+    // columns inside both ranges are hashed twice (at most 16 of them: one 16-wide chunk)
+    P.ov_begin = P.ov_end = 0;
+    if (a_any && b_any && P.b_begin < P.a_end) { P.ov_begin = P.b_begin; P.ov_end = P.a_end < P.b_end ? P.a_end : P.b_end; }
+}
+
+}  // namespace
+
+struct raisr_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // chroma lane of raisr_hip_process_host (overlaps the Y path)
+    // stream ring (raisr_hip_use_streams): caller-owned compute / upload / download streams shared by several contexts, so
+    // that a streamed job is a stage-ordered pipeline (all uploads in frame order on one stream, all downloads on another)
+    hipStream_t up = nullptr, down = nullptr;
+    hipStream_t own_stream = nullptr;          // the pooled stream `stream` replaced while a caller-owned one is in use
+    hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_done = nullptr;
+    bool done_pending = false;
+    bool legacy_pending = false;               // ring context that took the two-stream branch of process_host_async (rows != NULL)
+    bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
+    bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
+    int fast = 0;                              // NON-bit-exact fast mode (raisr_hip_set_fast / RAISR_HIP_FAST): 1 = exact buckets, filter stage on the matrix cores; 2 = also keeps the approximate tensor's bucket where it is not certified
+    bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
+    int n_cus = 256;                           // persistent k_filter_lds16 grid: one workgroup per CU (multiple of 4)
+    float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
+    FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
+    size_t fix_tiles = 0;
+    int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
+    unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
+    SepW sep{};
+    int keep_hash_plane = 0;                   // fused kernel also writes the hash plane (set by raisr_hip_debug_read_stage users)
+    raisr_hip_config cfg{};
+    int blending = RAISR_HIP_BLEND_COUNT;      // per-call BlendingMode (RNLProcess argument)
+    bool configured = false;
+    ModelDev model[2];
+    // shared small tables
+    uint2* d_tab14 = nullptr;
+    uint16_t* d_lut = nullptr;
+    uint16_t* d_tab16 = nullptr;                // rcpph T, rsqrtph T0, T1
+    GaussW16 gauss16{};
+    // scratch planes
+    void* d_lr[2] = {nullptr, nullptr};         // LR plane per pass, sample type (u8 for 8-bit content, else u16)
+    uint8_t* d_hash[2] = {nullptr, nullptr};    // first hash per pixel
+    uint8_t* d_hash2[2] = {nullptr, nullptr};   // [H][16] second hash of the tail (overlap) columns
+    float* d_hr[2] = {nullptr, nullptr};
+    void* d_mid = nullptr;                      // two-pass intermediate (sample type), only when the passes differ in size
+    int passW[2] = {0, 0}, passH[2] = {0, 0};
+    GaussW gauss{};
+    // device staging for raisr_hip_process_host
+    void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    hipEvent_t ev_chroma = nullptr;             // chroma lane done (packed-frame download waits for it)
+    KernelTimer timer;
+};
+
+namespace {
+
+void timer_begin(raisr_hip_ctx* c, const char* name, hipStream_t s, int& slot)
+{
+    slot = -1;
+    KernelTimer& T = c->timer;
+    if (!T.enabled || T.recs.size() >= T.cap) return;
+    int id = -1;
+    for (size_t i = 0; i < T.names.size(); i++) if (T.names[i] == name) { id = (int)i; break; }
+    if (id < 0) { T.names.push_back(name); id = (int)T.names.size() - 1; }
+    const size_t i = T.recs.size();
+    if (2 * i + 1 >= T.pool.size()) return;
+    KernelTimer::Rec r{id, T.pool[2 * i], T.pool[2 * i + 1]};
+    (void)hipEventRecord(r.a, s);
+    T.recs.push_back(r);
+    slot = (int)T.recs.size() - 1;
+}
+void timer_end(raisr_hip_ctx* c, hipStream_t s, int slot)
+{
+    if (slot >= 0) (void)hipEventRecord(c->timer.recs[slot].b, s);
+}
+
+ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch, int tie)
+{
+    ResizeParams R{};
+    R.sw = sw; R.sh = sh; R.dw = dw; R.dh = dh; R.spitch = spitch; R.dpitch = dpitch;
+    const int gx = gcd_int(sw, dw), gy = gcd_int(sh, dh);
+    R.Sx = sw / gx; R.Dx = dw / gx; R.Sy = sh / gy; R.Dy = dh / gy;
+    R.tie_even = tie == RAISR_HIP_TIE_HALF_EVEN;
+    return R;
+}
+
+template <typename TIn, typename TOut>
+void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, const ResizeParams& R, const char* name)
+{
+    int slot;
+    timer_begin(c, name, s, slot);
+    if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
+        dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else if (R.dw == R.sw && R.dh == R.sh) {
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_copy<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else {
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    }
+    timer_end(c, s, slot);
+}
+
+PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
+{
+    PassParams P{};
+    const raisr_hip_config& g = c->cfg;
+    const ModelDev& m = c->model[pass];
+    P.W = W; P.H = H;
+    P.lr_pitch = W; P.hash_pitch = W; P.hr_pitch = W;
+    P.lo = (float)g.clamp_lo; P.hi = (float)g.clamp_hi;
+    P.ilo = g.clamp_lo; P.ihi = g.clamp_hi;
+    column_plan(W, g.hash_variant, P);
+    P.hash2 = c->d_hash2[pass];
+    P.pixel_types = m.h.pixel_types;
+    P.randomness = c->blending == RAISR_HIP_BLEND_RANDOMNESS;
+    P.qangle = m.h.qangle;
+    P.qs0 = m.h.qstr[0]; P.qs1 = m.h.qstr[1];
+    P.qc0 = m.h.qcoh[0]; P.qc1 = m.h.qcoh[1];
+    P.bank = (const float*)((const char*)m.blob + kBlobHeader);
+    P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
+    P.tab14 = c->d_tab14;
+    P.lut_legacy = c->d_lut;
+    P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
+    P.gauss_dev = c->d_gauss;
+    return P;
+}
+
+// one RAISR pass on an LR plane already resident in c->d_lr[pass]
+template <typename TOut>
+void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+{
+    const int W = c->passW[pass], H = c->passH[pass];
+    PassParams P = make_pass(c, pass, W, H);
+    int slot;
+    if (P.c_final > kMargin && H > 2 * kMargin) {
+        constexpr int R = 4;        // rows per lane: 3..6 measure the same within noise, 8 is slower (occupancy)
+        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
+        dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
+        const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
+        if (c->fast || (c->fused && c->certify && c->split)) {
+            P.cert_stats = c->d_cert_stats;
+            P.cert_check = c->cert_check;
+            FixLists F = c->fix;
+            if (c->cert_check) {                     // self-check: remember which buckets were certified
+                if (!c->fix.cert_mask && hipMalloc((void**)&c->fix.cert_mask, (size_t)c->cfg.out_width * c->cfg.out_height) != hipSuccess) c->fix.cert_mask = nullptr;
+                F.cert_mask = c->fix.cert_mask;
+            } else F.cert_mask = nullptr;
+            F.tiles_x = (int)gf.x; F.tiles_y = (int)gf.y;
+            const unsigned ntiles = gf.x * gf.y;
+            const unsigned npers = ntiles < 1024u ? ntiles : 1024u;          // 4 workgroups per CU resident (LDS), each walks ~ntiles/1024 tiles
+            timer_begin(c, "k_hash_ac", s, slot);
+            hipLaunchKernelGGL((k_hash_ac<TOut>), dim3(npers), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->sep, F, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            if (c->fast < 2) {
+            timer_begin(c, "k_fix", s, slot);
+            hipLaunchKernelGGL((k_fix_sparse<TOut>), dim3((ntiles + 3u) / 4u), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, F, c->d_hash[pass], c->d_hash2[pass]);
+            const unsigned nd = (unsigned)(gf.x * gf.y < 2048u ? gf.x * gf.y : 2048u);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_fix_dense<TOut, false>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
+            else
+                hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            }
+            if (c->fast && c->model[pass].bank_mfma) {             // the panels are allocated by configure / set_fast (errors reported there)
+                ModelDev& m = c->model[pass];
+                if (!m.bank_mfma_valid) {
+                    hipLaunchKernelGGL(k_build_mfma_bank, dim3((unsigned)((kMfBankHalfs + 255) / 256)), dim3(256), 0, s, P.bank, m.bank_mfma);
+                    m.bank_mfma_valid = true;
+                }
+                {
+                    dim3 gm((P.c_final - kMargin + kMfW - 1) / kMfW, (H - 2 * kMargin + kMfH - 1) / kMfH);
+                    timer_begin(c, "k_filter_mfma", s, slot);
+#ifdef RAISR_HIP_DEV                                                  /* profiling aid of a development build (scripts/build_exp.sh dev -DRAISR_HIP_DEV) */
+                    static const int mpart = getenv("RAISR_HIP_MF_PART") ? atoi(getenv("RAISR_HIP_MF_PART")) : 0;
+                    if (mpart == 1) hipLaunchKernelGGL((k_filter_mfma<TOut, 1>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    else if (mpart == 2) hipLaunchKernelGGL((k_filter_mfma<TOut, 2>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    else
+#endif
+                    hipLaunchKernelGGL((k_filter_mfma<TOut>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    timer_end(c, s, slot);
+                }
+            } else if (c->lds_filter && c->cfg.bits <= 10) {      // samples above 10 bits are not exact in binary16: k_filter
+                const bool sp2 = P.pixel_types == 4;
+                const int wh = sp2 ? 41 : 26;
+                const size_t sh16 = (size_t)217 * 128 * 4 + 2 * (size_t)wh * (sp2 ? 286 : 154) * 2 + 4 * 1024;
+                timer_begin(c, "k_filter_lds16", s, slot);
+                if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                timer_end(c, s, slot);
+            } else {
+                timer_begin(c, "k_filter", s, slot);
+                hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                timer_end(c, s, slot);
+            }
+        } else if (c->fused && c->certify) {
+            P.write_hash = c->keep_hash_plane;
+            P.cert_stats = c->d_cert_stats;
+            P.cert_check = c->cert_check;
+            timer_begin(c, "k_hashfilter_ac", s, slot);
+#ifdef RAISR_HIP_DEV                                                  /* profiling aid of a development build: hash stage only / filter stage only */
+            static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
+            if (part == 2 && getenv("RAISR_HIP_AC_PATTERN")) P.cert_check = atoi(getenv("RAISR_HIP_AC_PATTERN"));
+            if (part == 1)
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            else if (part == 2)
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            else
+#endif
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else if (c->fused) {
+            P.write_hash = c->keep_hash_plane;
+            timer_begin(c, "k_hashfilter", s, slot);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_hashfilter<TOut, false>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+            else
+                hipLaunchKernelGGL((k_hashfilter<TOut, true>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else {
+            timer_begin(c, "k_hash", s, slot);
+            if (!avx2all)
+                hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+            else
+                hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_filter", s, slot);
+            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
+            timer_end(c, s, slot);
+        }
+    }
+    if (P.randomness) {
+        dim3 gb((W + 63) / 64, (H + 3) / 4);
+        timer_begin(c, "k_blend_rand", s, slot);
+        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        timer_end(c, s, slot);
+        return;
+    }
+    dim3 gb((W + 63) / 64, (H + 15) / 16);
+    timer_begin(c, "k_blend", s, slot);
+    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
+}
+
+// one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
+template <typename TOut>
+void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+{
+    const int W = c->passW[pass], H = c->passH[pass];
+    PassParams P = make_pass(c, pass, W, H);
+    const ModelDev& m = c->model[pass];
+    Pass16 Q{};
+    const int rows = m.h.hashkeys * m.h.pixel_types;
+    Q.bank16 = (const uint32_t*)((const char*)m.blob + kBlobHeader + blob_f32_bytes(rows));
+    Q.bank16_bytes = (int)blob_f16_bytes(rows);
+    Q.tab16 = c->d_tab16;
+    Q.qangle = m.h.qangle16; Q.qs0 = m.h.qstr16[0]; Q.qs1 = m.h.qstr16[1]; Q.qc0 = m.h.qcoh16[0]; Q.qc1 = m.h.qcoh16[1];
+    {   // NF_8 / NF_10 (Raisr_globals.h:208-209; Raisr_AVX512FP16.cpp:146-151)
+        const float maxv = c->cfg.bits == 8 ? 255.0f : 1023.0f;
+        volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
+        Q.nf = nf;
+    }
+    Q.c_avx = (W - 1) - ((W - 1) % 32) + 1;
+    int slot;
+    if (P.c_final > kMargin && H > 2 * kMargin) {
+        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
+        if (c->fused) {
+            P.write_hash = c->keep_hash_plane;
+            timer_begin(c, "k_hashfilter16", s, slot);
+            hipLaunchKernelGGL((k_hashfilter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass], (uint16_t*)c->d_hr[pass]);
+            timer_end(c, s, slot);
+        } else {
+            timer_begin(c, "k_hash16", s, slot);
+            hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
+            timer_end(c, s, slot);
+            timer_begin(c, "k_filter16", s, slot);
+            hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
+            timer_end(c, s, slot);
+        }
+    }
+    if (P.randomness) {
+        dim3 gr((W + 63) / 64, (H + 3) / 4);
+        timer_begin(c, "k_blend_rand", s, slot);
+        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        timer_end(c, s, slot);
+        return;
+    }
+    dim3 gb((W + 63) / 64, (H + 15) / 16);
+    timer_begin(c, "k_blend16", s, slot);
+    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
+}
+
+void free_scratch(raisr_hip_ctx* c)
+{
+    for (int i = 0; i < 2; i++) {
+        if (c->d_lr[i]) (void)hipFree(c->d_lr[i]);
+        if (c->d_hash[i]) (void)hipFree(c->d_hash[i]);
+        if (c->d_hash2[i]) (void)hipFree(c->d_hash2[i]);
+        if (c->d_hr[i]) (void)hipFree(c->d_hr[i]);
+        c->d_lr[i] = nullptr; c->d_hash[i] = nullptr; c->d_hash2[i] = nullptr; c->d_hr[i] = nullptr;
+    }
+    if (c->d_mid) (void)hipFree(c->d_mid);
+    c->d_mid = nullptr;
+    if (c->fix.counters) (void)hipFree(c->fix.counters);
+    if (c->fix.counts) (void)hipFree(c->fix.counts);
+    if (c->fix.sparse) (void)hipFree(c->fix.sparse);
+    if (c->fix.dense) (void)hipFree(c->fix.dense);
+    if (c->fix.cert_mask) (void)hipFree(c->fix.cert_mask);
+    c->fix = FixLists{};
+    c->fix_tiles = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* raisr_hip_last_error(void) { return g_err.c_str(); }
+void raisr_hip_destroy(raisr_hip_ctx* c);
+const char* raisr_hip_version(void) { return "raisr-hip 0.1 (gfx950)"; }
+
+int raisr_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// Streams and the host-plane staging buffer are recycled through process-wide pools instead of being destroyed with
+// their context: hosts such as FFmpeg re-create the filter per clip, and every create/destroy cycle should leave the
+// device exactly as it found it (tests/test_gpu_host_api.py::test_context_lifecycle_does_not_leak_device_memory).
+static std::mutex g_pool_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;      // (device, idle stream)
+
+static int pool_get_stream(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); i++)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return RAISR_HIP_OK;
+            }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return RAISR_HIP_OK;
+}
+
+static void pool_put_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_stream_pool.emplace_back(device, s);
+}
+
+struct StageBuf { int device; void* ptr; size_t bytes; };
+static std::vector<StageBuf> g_stage_pool;
+
+static void* pool_get_stage(int device, size_t need, size_t* got)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_stage_pool.size(); i++)
+            if (g_stage_pool[i].device == device && g_stage_pool[i].bytes >= need) {
+                void* p = g_stage_pool[i].ptr; *got = g_stage_pool[i].bytes;
+                g_stage_pool.erase(g_stage_pool.begin() + (long)i);
+                return p;
+            }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return nullptr;
+    *got = need;
+    return p;
+}
+
+static void pool_put_stage(int device, void* p, size_t bytes)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_stage_pool.size() >= 16) {               // bound the idle set: drop the smallest buffer
+        size_t k = 0;
+        for (size_t i = 1; i < g_stage_pool.size(); i++) if (g_stage_pool[i].bytes < g_stage_pool[k].bytes) k = i;
+        if (g_stage_pool[k].bytes < bytes) { (void)hipFree(g_stage_pool[k].ptr); g_stage_pool[k] = {device, p, bytes}; }
+        else (void)hipFree(p);
+        return;
+    }
+    g_stage_pool.push_back({device, p, bytes});
+}
+
+static int create_impl(raisr_hip_ctx* c)
+{
+    if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
+    if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
+    if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
+    if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 4) c->n_cus = prop.multiProcessorCount & ~3;
+        // k_filter_lds16 declares ~160 KB of dynamic LDS
+#ifdef RAISR_HIP_DEV
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
+#endif
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
+    int rc = pool_get_stream(c->device, &c->stream);
+    if (rc) return rc;
+    rc = pool_get_stream(c->device, &c->stream2);
+    if (rc) return rc;
+    // small shared tables
+    std::vector<uint2> tab(128);
+    for (int i = 0; i < 64; i++) { tab[i] = make_uint2(X86_RCP14_C0[i], X86_RCP14_C1[i]); tab[64 + i] = make_uint2(X86_RSQRT14_C0[i], X86_RSQRT14_C1[i]); }
+    std::vector<uint16_t> lut(4096);
+    for (int i = 0; i < 2048; i++) { lut[i] = X86_RCP_LUT[i]; lut[2048 + i] = X86_RSQRT_LUT[i]; }
+    HIP_TRY(hipMalloc((void**)&c->d_tab14, tab.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void**)&c->d_lut, lut.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(c->d_tab14, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> t16(3072);
+    for (int i = 0; i < 1024; i++) { t16[i] = X86_RCPPH_T[i]; t16[1024 + i] = X86_RSQRTPH_T0[i]; t16[2048 + i] = X86_RSQRTPH_T1[i]; }
+    HIP_TRY(hipMalloc((void**)&c->d_tab16, t16.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(c->d_tab16, t16.data(), t16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());           // (null-stream copies are not ordered with the non-blocking streams the kernels use)
+    {   // un-normalised Gaussian in binary16, (fp16)literal (Raisr_globals.h:267-278)
+        for (int i = 0; i < 11; i++)
+            for (int k = 0; k < 11; k++) {
+                const _Float16 wv = (_Float16)kGaussQ[i < 6 ? i : 10 - i][k < 6 ? k : 10 - k];
+                uint16_t u; memcpy(&u, &wv, 2);
+                c->gauss16.wT[k][i] = (uint32_t)u | ((uint32_t)u << 16);
+            }
+    }
+    return RAISR_HIP_OK;
+}
+
+
+int raisr_hip_create(raisr_hip_ctx** out, int device_index)
+{
+    if (!out) return fail(RAISR_HIP_EINVAL, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RAISR_HIP_ENODEV, "no HIP device visible", e);
+    if (device_index < 0 || device_index >= n) return fail(RAISR_HIP_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device_index));
+    raisr_hip_ctx* c = new raisr_hip_ctx();
+    c->device = device_index;
+    const int rc = create_impl(c);
+    if (rc != RAISR_HIP_OK) { const std::string keep = g_err; raisr_hip_destroy(c); g_err = keep; return rc; }
+    *out = c;
+    return RAISR_HIP_OK;
+}
+
+void raisr_hip_destroy(raisr_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->timer.pool) if (e) (void)hipEventDestroy(e);
+    free_scratch(c);
+    for (int i = 0; i < 2; i++) if (c->model[i].blob) (void)hipFree(c->model[i].blob);
+    for (int i = 0; i < 2; i++) if (c->model[i].bank_mfma) (void)hipFree(c->model[i].bank_mfma);
+    if (c->d_tab14) (void)hipFree(c->d_tab14);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_tab16) (void)hipFree(c->d_tab16);
+    if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
+    if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->own_stream) { c->stream = c->own_stream; c->own_stream = nullptr; }
+    if (c->d_gauss) (void)hipFree(c->d_gauss);
+    pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
+    pool_put_stream(c->device, c->stream);
+    pool_put_stream(c->device, c->stream2);
+    delete c;
+}
+
+size_t raisr_hip_model_blob_bytes(int hashkeys, int pixel_types)
+{
+    if (hashkeys <= 0 || pixel_types <= 0) return 0;
+    const int rows = hashkeys * pixel_types;
+    return (size_t)kBlobHeader + blob_f32_bytes(rows) + blob_f16_bytes(rows);
+}
+
+int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, int pixel_types,
+                              const double qstr[2], const double qcoh[2], int quant_angle)
+{
+    if (!host_blob || !bank || !qstr || !qcoh) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (hashkeys <= 0 || hashkeys > 255 || (pixel_types != 1 && pixel_types != 4) || quant_angle <= 0)
+        return fail(RAISR_HIP_EINVAL, "unsupported model geometry");
+    auto hbits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    BlobHeader h{};
+    h.magic = kBlobMagic; h.hashkeys = hashkeys; h.pixel_types = pixel_types; h.quant_angle = quant_angle;
+    h.qangle = (float)quant_angle / 3.141592653f;           // gQAngle, Raisr.cpp:1553
+    for (int i = 0; i < 2; i++) {
+        h.qstr[i] = (float)qstr[i]; h.qcoh[i] = (float)qcoh[i];                 // (float)stod(token), Raisr.cpp:377,413
+        h.qstr16[i] = hbits((_Float16)qstr[i]); h.qcoh16[i] = hbits((_Float16)qcoh[i]);   // (_Float16)stod(token)
+    }
+    h.qangle16 = hbits((_Float16)h.qangle);                 // _mm512_set1_ph(gQAngle)
+    memcpy(host_blob, &h, sizeof h);
+    const size_t rows = (size_t)hashkeys * pixel_types;
+    float* dst = (float*)((char*)host_blob + kBlobHeader);
+    memset(dst, 0, blob_f32_bytes((int)rows));
+    for (size_t r = 0; r < rows; r++) memcpy(dst + r * kTapsPad, bank + r * kTaps, kTaps * sizeof(float));
+    // binary16 bank (Raisr.cpp:344-350: currentfilter[j] = (_Float16)weight), lane-pair interleaved
+    uint16_t* d16 = (uint16_t*)((char*)host_blob + kBlobHeader + blob_f32_bytes((int)rows));
+    for (size_t r = 0; r < rows; r++)
+        for (int ch = 0; ch < 4; ch++)
+            for (int l = 0; l < 16; l++) {
+                const int k0 = 32 * ch + l, k1 = k0 + 16;
+                d16[(r * 64 + ch * 16 + l) * 2 + 0] = k0 < kTaps ? hbits((_Float16)bank[r * kTaps + k0]) : (uint16_t)0;
+                d16[(r * 64 + ch * 16 + l) * 2 + 1] = k1 < kTaps ? hbits((_Float16)bank[r * kTaps + k1]) : (uint16_t)0;
+            }
+    return RAISR_HIP_OK;
+}
+
+// Bucket of the all-zero structure tensor (flat windows) in both hash flavours, from the device's exact hash code:
+// the certified hash stage looks it up instead of hashing (0, 0, 0) per pixel.
+static int compute_zero_buckets(raisr_hip_ctx* c, int pass_index)
+{
+    ModelDev& m = c->model[pass_index];
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, 2) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    uint8_t h[2] = {0, 0};
+    if (hipMemsetAsync(d_in, 0, 3 * sizeof(float), c->stream) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemset");   // stream-ordered before k_debug_hash
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    for (int legacy = 0; legacy < 2 && !rc; legacy++) {
+        hipLaunchKernelGGL(k_debug_hash, dim3(1), dim3(256), 0, c->stream, d_in, 1u, P, legacy, d_out + legacy);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_hash");
+    }
+    if (!rc && hipMemcpy(h, d_out, 2, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    m.zero_bucket[0] = h[0]; m.zero_bucket[1] = h[1];
+    return rc;
+}
+
+int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void* device_blob, size_t bytes, void* stream)
+{
+    if (!c || !device_blob || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (bytes < (size_t)kBlobHeader) return fail(RAISR_HIP_EINVAL, "model blob shorter than its header");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    BlobHeader h{};
+    HIP_TRY(hipMemcpyAsync(&h, device_blob, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h.magic != kBlobMagic || h.hashkeys <= 0 || h.hashkeys > 255 || (h.pixel_types != 1 && h.pixel_types != 4) ||
+        raisr_hip_model_blob_bytes(h.hashkeys, h.pixel_types) != bytes)
+        return fail(RAISR_HIP_EINVAL, "model blob corrupted");
+    ModelDev& m = c->model[pass_index];
+    if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
+    if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
+    HIP_TRY(hipMemcpyAsync(m.blob, device_blob, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m.bytes = bytes; m.h = h; m.valid = true; m.bank_mfma_valid = false;
+    return compute_zero_buckets(c, pass_index);
+}
+
+// Multi-GPU start-up: the one collective of the path.  RCCL is resolved on first use, so a single-GPU consumer of
+// this library carries no librccl dependency; the handful of declarations below are RCCL's stable C ABI (rccl.h).
+int raisr_hip_broadcast_model_blob(void* nccl_comm, int root, void* device_blob, size_t bytes, void* stream)
+{
+    if (!nccl_comm || !device_blob || bytes < (size_t)kBlobHeader || root < 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    static std::mutex mu;
+    static bcast_fn bcast = nullptr;
+    static errstr_fn errstr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!bcast) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return fail(RAISR_HIP_ERUNTIME, "librccl.so not found (needed only for the multi-GPU model broadcast)");
+            bcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
+            errstr = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+            if (!bcast) return fail(RAISR_HIP_ERUNTIME, "ncclBroadcast not exported by librccl");
+        }
+    }
+    const int kNcclUint8 = 1;                                         // ncclDataType_t
+    const int rc = bcast(device_blob, device_blob, bytes, kNcclUint8, root, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) {
+        g_err = std::string("ncclBroadcast: ") + (errstr ? errstr(rc) : "error");
+        return RAISR_HIP_ERUNTIME;
+    }
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,
+                        const double qstr[2], const double qcoh[2], int quant_angle)
+{
+    if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    const size_t bytes = raisr_hip_model_blob_bytes(hashkeys, pixel_types);
+    if (!bytes) return fail(RAISR_HIP_EINVAL, "bad model geometry");
+    std::vector<char> host(bytes);
+    int rc = raisr_hip_pack_model_blob(host.data(), bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    ModelDev& m = c->model[pass_index];
+    if (m.blob && m.bytes != bytes) { (void)hipFree(m.blob); m.blob = nullptr; }
+    if (!m.blob) { if (hipMalloc(&m.blob, bytes) != hipSuccess) return fail(RAISR_HIP_ENOMEM, "model blob alloc"); }
+    HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());           // frames run on non-blocking streams, which nothing orders after a null-stream copy
+    m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true; m.bank_mfma_valid = false;
+    return compute_zero_buckets(c, pass_index);
+}
+
+static bool fast_mode_supported(const raisr_hip_config* cfg)
+{
+    return cfg->use_pixel_type && cfg->bits <= 10 && cfg->hash_variant != RAISR_HIP_HASH_FP16;
+}
+
+// B panels of k_filter_mfma for every pass in use (590 KB each); filled on the stream by the first frame that needs them
+static int alloc_fast_banks(raisr_hip_ctx* c, int passes)
+{
+    for (int p = 0; p < passes; p++) {
+        ModelDev& m = c->model[p];
+        if (!m.bank_mfma) {
+            if (hipMalloc((void**)&m.bank_mfma, kMfBankHalfs * sizeof(_Float16)) != hipSuccess) { m.bank_mfma = nullptr; return fail(RAISR_HIP_ENOMEM, "fast mode: filter panel alloc"); }
+            m.bank_mfma_valid = false;
+        }
+    }
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_fast(raisr_hip_ctx* c, int on)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (on && c->configured && !fast_mode_supported(&c->cfg))
+        return fail(RAISR_HIP_EINVAL, "fast mode (matrix-core filter stage) supports ratio 2, 8/10-bit content and the fp32 flavours only");
+    if (on > 0 && c->configured) {
+        HIP_TRY(hipSetDevice(c->device));
+        const int rc = alloc_fast_banks(c, c->cfg.passes);
+        if (rc) return rc;
+    }
+    c->fast = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_get_fast(const raisr_hip_ctx* c) { return c ? c->fast : 0; }
+
+int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
+{
+    if (!c || !cfg) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (cfg->bits != 8 && cfg->bits != 10 && cfg->bits != 16) return fail(RAISR_HIP_EINVAL, "bits must be 8, 10 or 16");
+    if (cfg->passes != 1 && cfg->passes != 2) return fail(RAISR_HIP_EINVAL, "passes must be 1 or 2");
+    if (cfg->in_width <= 0 || cfg->in_height <= 0 || cfg->out_width <= 0 || cfg->out_height <= 0)
+        return fail(RAISR_HIP_EINVAL, "bad plane size");
+    if ((uint64_t)cfg->out_width * (uint64_t)cfg->out_height >= (1ull << 31) || (uint64_t)cfg->in_width * (uint64_t)cfg->in_height >= (1ull << 31))
+        return fail(RAISR_HIP_EINVAL, "planes of 2^31 samples or more are not supported (32-bit element offsets)");
+    if (cfg->clamp_lo < 0 || cfg->clamp_hi <= cfg->clamp_lo || cfg->clamp_hi >= (1 << cfg->bits))
+        return fail(RAISR_HIP_EINVAL, "clamp range must satisfy 0 <= lo < hi < 2^bits");
+    if (cfg->hash_variant != RAISR_HIP_HASH_AVX2 && cfg->hash_variant != RAISR_HIP_HASH_AVX512 &&
+        cfg->hash_variant != RAISR_HIP_HASH_FP16)
+        return fail(RAISR_HIP_EINVAL, "unknown hash variant");
+    if (cfg->hash_variant == RAISR_HIP_HASH_FP16 && cfg->bits > 10)
+        return fail(RAISR_HIP_EINVAL, "the binary16 pipeline supports 8- and 10-bit content (16-bit samples are not exact in binary16)");
+    if (cfg->blending != RAISR_HIP_BLEND_COUNT && cfg->blending != RAISR_HIP_BLEND_RANDOMNESS)
+        return fail(RAISR_HIP_EINVAL, "blending must be 1 (Randomness) or 2 (CountOfBitsChanged)");
+    if (!c->model[0].valid || (cfg->passes == 2 && !c->model[1].valid)) return fail(RAISR_HIP_ESTATE, "model not set");
+    for (int p = 0; p < cfg->passes; p++)
+        if (c->model[p].h.pixel_types != (cfg->use_pixel_type ? 4 : 1))
+            return fail(RAISR_HIP_EINVAL, "model pixel types do not match ratio");
+    if (c->fast && !fast_mode_supported(cfg))
+        return fail(RAISR_HIP_EINVAL, "fast mode (matrix-core filter stage) supports ratio 2, 8/10-bit content and the fp32 flavours only");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_scratch(c);
+    c->configured = false;                     // until every allocation below has succeeded: a failed configure leaves nothing to run on
+    c->cfg = *cfg;
+    c->gauss = make_gauss(cfg->bits);
+    c->sep = make_sep(c->gauss);
+    HIP_TRY(hipMemcpy(c->d_gauss, &c->gauss, sizeof(GaussW), hipMemcpyHostToDevice));
+    const bool mode2 = cfg->passes == 2 && cfg->two_pass_mode == 2;
+    c->passW[0] = mode2 ? cfg->in_width : cfg->out_width;
+    c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
+    c->passW[1] = cfg->out_width; c->passH[1] = cfg->out_height;
+    const size_t bps = cfg->bits == 8 ? 1 : 2;
+    for (int p = 0; p < cfg->passes; p++) {
+        const size_t n = (size_t)c->passW[p] * c->passH[p];
+        if (hipMalloc((void**)&c->d_lr[p], n * bps) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash[p], n) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash2[p], (size_t)c->passH[p] * 16) != hipSuccess ||
+            hipMalloc((void**)&c->d_hr[p], n * sizeof(float)) != hipSuccess) {
+            free_scratch(c);
+            return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
+        }
+    }
+    if (cfg->hash_variant != RAISR_HIP_HASH_FP16) {   // worklists of the split pipeline (largest pass geometry)
+        size_t tiles = 0;
+        for (int p = 0; p < cfg->passes; p++) {
+            const size_t t = (size_t)((c->passW[p] + 63) / 64) * (size_t)((c->passH[p] + 15) / 16);
+            if (t > tiles) tiles = t;
+        }
+        c->fix_tiles = tiles;
+        if (hipMalloc((void**)&c->fix.counters, 2 * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.counts, tiles * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.sparse, tiles * kSparseMax * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&c->fix.dense, tiles * sizeof(unsigned)) != hipSuccess) {
+            free_scratch(c);
+            return fail(RAISR_HIP_ENOMEM, "worklist alloc");
+        }
+        HIP_TRY(hipMemsetAsync(c->fix.counters, 0, 2 * sizeof(unsigned), c->stream));
+    }
+    if (cfg->passes == 2) {
+        // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
+        HIP_TRY(hipMemsetAsync(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * bps, c->stream));
+        if (c->passW[0] != c->passW[1] || c->passH[0] != c->passH[1]) {
+            const size_t n = (size_t)c->passW[0] * c->passH[0];
+            if (hipMalloc((void**)&c->d_mid, n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
+            HIP_TRY(hipMemsetAsync(c->d_mid, 0, n * bps, c->stream));
+        }
+    }
+    if (c->fast) {
+        const int rc = alloc_fast_banks(c, cfg->passes);
+        if (rc) { free_scratch(c); return rc; }
+    }
+    // The clears above must have LANDED before any frame runs: frames may be enqueued on other (non-blocking) streams -- the
+    // ring's, a caller's -- which are not ordered after this one, and a null-stream hipMemset is not ordered with them either
+    // (a clear overtaking a frame's pass-1 output showed up as a 1-in-5 mismatch of a small 2-pass test).
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    c->blending = cfg->blending;
+    c->configured = true;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_set_blending(raisr_hip_ctx* c, int blending)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    if (blending != RAISR_HIP_BLEND_COUNT && blending != RAISR_HIP_BLEND_RANDOMNESS)
+        return fail(RAISR_HIP_EINVAL, "blending must be 1 (Randomness) or 2 (CountOfBitsChanged)");
+    c->blending = blending;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream)
+{
+    if (!c || !d_in || !d_out) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const raisr_hip_config& g = c->cfg;
+    const int bps = g.bits == 8 ? 1 : 2;
+    if (in_pitch % bps || out_pitch % bps) return fail(RAISR_HIP_EINVAL, "pitch not a multiple of the sample size");
+    const int ipe = (int)(in_pitch / bps), ope = (int)(out_pitch / bps);
+
+    // Every plane of the pipeline (LR, two-pass intermediate, output) has the sample type of the content:
+    // u8 for 8-bit, u16 above.  pass-1 LR = cheap upscale of the input (a copy when pass 1 runs at input size).
+    const bool fp16 = g.hash_variant == RAISR_HIP_HASH_FP16;
+    const bool same = g.passes == 2 && c->passW[0] == c->passW[1] && c->passH[0] == c->passH[1];
+    auto job = [&](auto tag) {
+        using T = decltype(tag);
+        ResizeParams R0 = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
+        launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
+        if (g.passes == 1) {
+            if (fp16) run_pass16<T>(c, s, 0, d_out, ope); else run_pass<T>(c, s, 0, d_out, ope);
+            return;
+        }
+        // pass 1 writes the integer intermediate (Raisr.cpp:927-934).  When both passes run at output size
+        // (mode 1) the intermediate IS pass 2's LR plane; in mode 2 it is upscaled now (Raisr.cpp:945-975).
+        void* mid = same ? c->d_lr[1] : c->d_mid;
+        if (fp16) run_pass16<T>(c, s, 0, mid, c->passW[0]); else run_pass<T>(c, s, 0, mid, c->passW[0]);
+        if (!same) {
+            ResizeParams R1 = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
+            launch_resize<T, T>(c, s, c->d_mid, c->d_lr[1], R1, "k_resize");
+        }
+        if (fp16) run_pass16<T>(c, s, 1, d_out, ope); else run_pass<T>(c, s, 1, d_out, ope);
+    };
+    if (bps == 1) job(uint8_t{}); else job(uint16_t{});
+    HIP_TRY(hipGetLastError());
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_resize_plane_device(raisr_hip_ctx* c, const void* d_src, int sw, int sh, size_t spitch,
+                                  void* d_dst, int dw, int dh, size_t dpitch, int bits, void* stream)
+{
+    if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int bps = bits == 8 ? 1 : 2;
+    ResizeParams R = make_resize(sw, sh, (int)(spitch / bps), dw, dh, (int)(dpitch / bps), c->configured ? c->cfg.tie_rule : 0);
+    if (bps == 1) launch_resize<uint8_t, uint8_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
+    else launch_resize<uint16_t, uint16_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
+    HIP_TRY(hipGetLastError());
+    return RAISR_HIP_OK;
+}
+
+// Whole device-resident yuv frame (the zero-copy analogue of the reference's vf_raisr_opencl path): RAISR on Y,
+// cheap upscale on both chroma planes, all enqueued on `stream`.
+int raisr_hip_process_frame_device(raisr_hip_ctx* c,
+                                   const void* d_in_y, size_t in_y_pitch, void* d_out_y, size_t out_y_pitch,
+                                   const void* d_in_u, const void* d_in_v, size_t in_c_pitch,
+                                   void* d_out_u, void* d_out_v, size_t out_c_pitch,
+                                   int cin_w, int cin_h, int cout_w, int cout_h, void* stream)
+{
+    if (!c || !d_in_u || !d_in_v || !d_out_u || !d_out_v) return fail(RAISR_HIP_EINVAL, "null plane");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    int rc = raisr_hip_process_y_device(c, d_in_y, in_y_pitch, d_out_y, out_y_pitch, stream);
+    if (rc) return rc;
+    rc = raisr_hip_resize_plane_device(c, d_in_u, cin_w, cin_h, in_c_pitch, d_out_u, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+    if (rc) return rc;
+    return raisr_hip_resize_plane_device(c, d_in_v, cin_w, cin_h, in_c_pitch, d_out_v, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+}
+
+int raisr_hip_synchronize(raisr_hip_ctx* c)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->up) {                               // shared streams: wait for this context's last frame only
+        if (c->done_pending) { HIP_TRY(hipEventSynchronize(c->ev_done)); c->done_pending = false; }
+        if (c->legacy_pending) {               // a banded frame (rows != NULL) went through the context's own stream pair
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream2));
+            c->legacy_pending = false;
+        }
+        return RAISR_HIP_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_use_streams(raisr_hip_ctx* c, void* compute, void* upload, void* download)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->up) { if (c->done_pending) { HIP_TRY(hipEventSynchronize(c->ev_done)); c->done_pending = false; } }
+    else { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2)); }
+    if (!compute && !upload && !download) {    // back to the context's own streams
+        if (c->own_stream) { c->stream = c->own_stream; c->own_stream = nullptr; }
+        c->up = c->down = nullptr;
+        return RAISR_HIP_OK;
+    }
+    if (!compute || !upload || !download) return fail(RAISR_HIP_EINVAL, "compute, upload and download streams go together");
+    if (!c->ev_up) HIP_TRY(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+    if (!c->ev_comp) HIP_TRY(hipEventCreateWithFlags(&c->ev_comp, hipEventDisableTiming));
+    if (!c->ev_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    if (!c->own_stream) c->own_stream = c->stream;
+    c->stream = (hipStream_t)compute; c->up = (hipStream_t)upload; c->down = (hipStream_t)download;
+    c->done_pending = false;
+    return RAISR_HIP_OK;
+}
+
+// Band plan: see include/raisr_hip.h.  Validity of the kept rows (output rows, counted from an ARTIFICIAL
+// sub-frame border; a real frame border needs no padding):
+//   cheap upscale only      the first/last output rows interpolate against a replicated input row      -> 1 input row
+//   one pass                LR row 0 is wrong (replicated input row); HR row q reads LR rows q-6..q+6 and is
+//                           unfiltered for q < 6; the blend of row r reads HR rows r-1..r+1           -> r >= 8 output rows
+//   two passes, mode 1      pass 2 reads pass-1 rows r-7..r+7, which must be valid themselves          -> r >= 16
+//   two passes, mode 2      pass 1 (input size) valid from input row 7, upscaled, then as one pass     -> 12 (2x) / 14 (1.5x) input rows
+// The padding below (6 input rows for one pass at 2x, 16 for two, 2 for chroma) covers these with margin; it is
+// a multiple of the alignment unit so that band starts keep the upscale phase and the pixel-type parity.
+int raisr_hip_plan_bands(int in_height, int out_height, int passes, int nbands, raisr_hip_band* bands)
+{
+    if (in_height <= 0 || out_height <= 0 || passes < 0 || passes > 2 || nbands < 1 || !bands) return fail(RAISR_HIP_EINVAL, "bad band request");
+    const int g = gcd_int(in_height, out_height);
+    const int num = out_height / g, den = in_height / g;
+    const int align = (den % 2 == 0) ? den : 2 * den;         // band starts: whole upscale periods, even rows
+    // input rows of padding at an artificial border: the validity distances above, converted to input rows, plus margin
+    const int out8 = (8 * den + num - 1) / num;                // 8 output rows in input rows, rounded up
+    int pad = passes == 0 ? 2 : (passes == 1 ? out8 + 2 : 9 + out8 + 3);
+    pad = (pad + align - 1) / align * align;
+    int K = nbands;
+    const int min_rows = 2 * pad + 2 * align;                  // a band keeps at least this many input rows
+    if (align > 32 || in_height / min_rows < 2) K = 1;
+    else if (K > in_height / min_rows) K = in_height / min_rows;
+    for (int k = 0; k < K; k++) {
+        const int s0 = k == 0 ? 0 : (int)((long long)in_height * k / K) / align * align;
+        const int s1 = k == K - 1 ? in_height : (int)((long long)in_height * (k + 1) / K) / align * align;
+        raisr_hip_band& b = bands[k];
+        b.in_row_begin = s0 - pad > 0 ? s0 - pad : 0;
+        const int in_end = s1 + pad < in_height ? s1 + pad : in_height;
+        b.in_row_count = in_end - b.in_row_begin;
+        b.out_row_begin = (int)((long long)b.in_row_begin * num / den);
+        const int out_end = in_end == in_height ? out_height : (int)((long long)in_end * num / den);
+        b.out_row_count = out_end - b.out_row_begin;
+        b.keep_begin = (int)((long long)s0 * num / den);
+        b.keep_count = (s1 == in_height ? out_height : (int)((long long)s1 * num / den)) - b.keep_begin;
+    }
+    return K;
+}
+
+// 2-D plane copy; contiguous planes (pitch == row bytes on both sides) go as one 1-D copy
+static hipError_t copy_plane(void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes, size_t rows,
+                             hipMemcpyKind kind, hipStream_t s)
+{
+    if (dpitch == row_bytes && spitch == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
+}
+
+int raisr_hip_process_host(raisr_hip_ctx* c,
+                           const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
+                           const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
+                           const void* in_v, size_t in_v_pitch, void* out_v, size_t out_v_pitch,
+                           int cin_w, int cin_h, int cout_w, int cout_h)
+{
+    const int rc = raisr_hip_process_host_async(c, in_y, in_y_pitch, out_y, out_y_pitch, in_u, in_u_pitch, out_u, out_u_pitch,
+                                                in_v, in_v_pitch, out_v, out_v_pitch, cin_w, cin_h, cout_w, cout_h, nullptr);
+    if (rc) return rc;
+    return raisr_hip_synchronize(c);
+}
+
+int raisr_hip_process_host_async(raisr_hip_ctx* c,
+                                 const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
+                                 const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
+                                 const void* in_v, size_t in_v_pitch, void* out_v, size_t out_v_pitch,
+                                 int cin_w, int cin_h, int cout_w, int cout_h, const raisr_hip_rows* rows)
+{
+    if (!c || !in_y || !out_y) return fail(RAISR_HIP_EINVAL, "null plane");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    HIP_TRY(hipSetDevice(c->device));
+    const raisr_hip_config& g = c->cfg;
+    const int bps = g.bits == 8 ? 1 : 2;
+    const bool chroma = in_u && out_u && in_v && out_v && cin_w > 0 && cin_h > 0 && cout_w > 0 && cout_h > 0;
+    const int y_skip = rows ? rows->y_skip : 0, y_keep = rows ? rows->y_keep : g.out_height;
+    const int c_skip = rows ? rows->c_skip : 0, c_keep = rows ? rows->c_keep : cout_h;
+    const int stage = rows ? rows->stage : 0;
+    if (stage < 0 || stage > 2) return fail(RAISR_HIP_EINVAL, "bad stage");
+    const bool do_up = stage != 2, do_down = stage != 1;
+    if (y_skip < 0 || y_keep < 0 || y_skip + y_keep > g.out_height || (chroma && (c_skip < 0 || c_keep < 0 || c_skip + c_keep > cout_h)))
+        return fail(RAISR_HIP_EINVAL, "row window outside the plane");
+    // tightly packed device staging: [inY][inU][inV][outY][outU][outV]
+    const size_t iy = (size_t)g.in_width * g.in_height * bps, oy = (size_t)g.out_width * g.out_height * bps;
+    const size_t ic = chroma ? (size_t)cin_w * cin_h * bps : 0, oc = chroma ? (size_t)cout_w * cout_h * bps : 0;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t off_iu = al(iy), off_iv = off_iu + al(ic), off_oy = off_iv + al(ic), off_ou = off_oy + al(oy), off_ov = off_ou + al(oc);
+    const size_t total = off_ov + al(oc);
+    if (c->d_stage_bytes < total) {
+        pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
+        c->d_stage_bytes = 0;
+        c->d_stage = pool_get_stage(c->device, total, &c->d_stage_bytes);
+        if (!c->d_stage) return fail(RAISR_HIP_ENOMEM, "staging alloc");
+        // the alignment gaps between the staged planes travel to the host with a packed-frame download: never another job's bytes
+        HIP_TRY(hipMemsetAsync(c->d_stage, 0, c->d_stage_bytes, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    char* d = (char*)c->d_stage;
+    if (c->up && !rows) {
+        // stage-ordered pipeline of the stream ring: uploads on the shared upload stream, kernels (Y, then the two cheap chroma
+        // upscales) on the compute stream, one download on the shared download stream; events carry the dependencies on the device
+        const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
+        const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
+        hipStream_t s = c->stream;
+        HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, c->up));
+        if (c->blending == RAISR_HIP_BLEND_RANDOMNESS)
+            HIP_TRY(copy_plane(d + off_oy, orow, out_y, out_y_pitch, orow, g.out_height, hipMemcpyHostToDevice, c->up));
+        if (chroma) {
+            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
+            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
+        }
+        // (kept also when upload and compute stream are the same: without this marker and the one before the download the same
+        //  ring measures 2.3-3.6 k fps instead of 3.9-4.2 k -- the runtime batches the stream's commands differently)
+        HIP_TRY(hipEventRecord(c->ev_up, c->up));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_up, 0));
+        int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
+        if (rc) return rc;
+        if (chroma) {
+            rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s);
+            if (rc) return rc;
+            rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s);
+            if (rc) return rc;
+        }
+        if (c->down != s) {                    // (measured: a download behind a cross-stream event, or in a pipeline whose uploads run on a
+            HIP_TRY(hipEventRecord(c->ev_comp, s));                     //  shared upload stream, is executed by a copy KERNEL, not the DMA
+            HIP_TRY(hipStreamWaitEvent(c->down, c->ev_comp, 0));        //  engine -- the ring passes one stream for all three roles)
+        } else {
+            HIP_TRY(hipEventRecord(c->ev_comp, c->stream2));            // marker between the last kernel and the download (see above)
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_comp, 0));
+        }
+        const bool packed = chroma && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
+                            (const char*)out_u == (const char*)out_y + (off_ou - off_oy) && (const char*)out_v == (const char*)out_y + (off_ov - off_oy);
+        if (packed) {
+            HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, c->down));
+        } else {
+            HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy, orow, orow, g.out_height, hipMemcpyDeviceToHost, c->down));
+            if (chroma) {
+                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
+                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
+            }
+        }
+        HIP_TRY(hipEventRecord(c->ev_done, c->down));
+        c->done_pending = true;
+        return RAISR_HIP_OK;
+    }
+    hipStream_t s = c->stream, s2 = c->stream2;
+    if (c->up) c->legacy_pending = true;       // raisr_hip_synchronize must wait for these two streams as well
+    // Y: upload, RAISR passes, download on the context stream; chroma (plain cheap upscale, Raisr.cpp:1373-1388)
+    // runs on a second stream so its PCIe transfers overlap the Y kernels.
+    const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
+    const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
+    if (do_up) {
+        HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
+        if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
+            HIP_TRY(copy_plane(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
+        int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
+        if (rc) return rc;
+        if (chroma) {
+            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+            rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+        }
+    }
+    if (do_down) {
+        // Packed output frame: when the caller's three output planes sit in host memory exactly as the staging planes sit in
+        // device memory (raisr_hip_packed_frame_layout), the whole frame goes back as ONE copy -- fewer, larger PCIe
+        // transfers (the download is what bounds a streamed 4K job: 12.4 MB per frame).
+        const bool packed = chroma && !rows && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
+                            (const char*)out_u == (const char*)out_y + (off_ou - off_oy) && (const char*)out_v == (const char*)out_y + (off_ov - off_oy);
+        if (packed) {
+            if (!c->ev_chroma) HIP_TRY(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->ev_chroma, s2));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_chroma, 0));
+            HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, s));
+        } else {
+            if (chroma && c_keep > 0) {
+                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            }
+            if (y_keep > 0) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
+        }
+    }
+    return RAISR_HIP_OK;
+}
+
+// Byte offsets of the Y, U and V planes of a packed frame (tight pitches; each plane starts on a 256-byte boundary) and its
+// total size: the host-side layout raisr_hip_process_host* recognises and downloads (uploads) as one copy.
+int raisr_hip_packed_frame_layout(int y_w, int y_h, int c_w, int c_h, int bits, size_t offsets[3], size_t* total_bytes)
+{
+    if (y_w <= 0 || y_h <= 0 || c_w < 0 || c_h < 0 || !offsets || !total_bytes) return fail(RAISR_HIP_EINVAL, "bad argument");
+    const size_t bps = bits == 8 ? 1 : 2;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t ny = (size_t)y_w * y_h * bps, nc = (size_t)c_w * c_h * bps;
+    offsets[0] = 0; offsets[1] = al(ny); offsets[2] = offsets[1] + al(nc);
+    *total_bytes = offsets[2] + nc;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_keep_stages(raisr_hip_ctx* c, int on)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    c->keep_hash_plane = on != 0;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_read_stage(raisr_hip_ctx* c, int pass_index, uint8_t* hash_out, float* hr_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (!c->configured || !c->d_hash[pass_index]) return fail(RAISR_HIP_ESTATE, "pass not configured");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = (size_t)c->passW[pass_index] * c->passH[pass_index];
+    if (hash_out) HIP_TRY(hipMemcpy(hash_out, c->d_hash[pass_index], n, hipMemcpyDeviceToHost));
+    if (hr_out) HIP_TRY(hipMemcpy(hr_out, c->d_hr[pass_index], n * sizeof(float), hipMemcpyDeviceToHost));
+    return RAISR_HIP_OK;
+}
+
+// Certified hash stage: statistics and self-check (see include/raisr_hip.h).
+int raisr_hip_debug_certify(raisr_hip_ctx* c, int collect, int check)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (collect && !c->d_cert_stats) HIP_TRY(hipMalloc((void**)&c->d_cert_stats, 3 * sizeof(unsigned)));
+    if (c->d_cert_stats) { HIP_TRY(hipMemsetAsync(c->d_cert_stats, 0, 3 * sizeof(unsigned), c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    if (!collect && c->d_cert_stats) { (void)hipFree(c->d_cert_stats); c->d_cert_stats = nullptr; }
+    c->cert_check = check != 0;
+    return RAISR_HIP_OK;
+}
+
+int raisr_hip_debug_certify_stats(raisr_hip_ctx* c, unsigned out[3])
+{
+    if (!c || !out) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (!c->d_cert_stats) return fail(RAISR_HIP_ESTATE, "statistics are not being collected");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_cert_stats, 3 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return RAISR_HIP_OK;
+}
+
+// Test hook: decision of the certified hash stage for n host-side approximate tensor triples (see include/raisr_hip.h).
+int raisr_hip_debug_approx_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, const float* abd, size_t n,
+                                uint8_t* bucket_out, uint8_t* cert_out, float* eps_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1 || !abd || !bucket_out || !cert_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (hash_flavour != RAISR_HIP_HASH_AVX512 && hash_flavour != RAISR_HIP_HASH_AVX2) return fail(RAISR_HIP_EINVAL, "hash_flavour must be AVX512 or AVX2");
+    if (!c->model[pass_index].blob || !c->configured) return fail(RAISR_HIP_ESTATE, "set the model and configure first");
+    if (eps_out) *eps_out = c->sep.eEb * 2.0f;             // the eps of the tensor bounds (eEb = eps / 2)
+    if (n == 0) return RAISR_HIP_OK;
+    if (n > 0x7fffffffu / 3) return fail(RAISR_HIP_EINVAL, "too many triples");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, 2 * n) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipDeviceSynchronize");
+    if (!rc) {
+        hipLaunchKernelGGL(k_debug_approx_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P, c->sep,
+                           hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out, d_out + n);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_approx_hash");
+    }
+    if (!rc && (hipMemcpy(bucket_out, d_out, n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(cert_out, d_out + n, n, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
+
+// Test hook: hash bucket of n host-side (a, b, d) triples with pass `pass_index`'s thresholds, computed by the
+// device functions k_hash uses (hash_flavour: RAISR_HIP_HASH_AVX512 or RAISR_HIP_HASH_AVX2).
+int raisr_hip_debug_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, const float* abd, size_t n, uint8_t* hash_out)
+{
+    if (!c || pass_index < 0 || pass_index > 1 || !abd || !hash_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (hash_flavour != RAISR_HIP_HASH_AVX512 && hash_flavour != RAISR_HIP_HASH_AVX2) return fail(RAISR_HIP_EINVAL, "hash_flavour must be AVX512 or AVX2");
+    if (!c->model[pass_index].blob) return fail(RAISR_HIP_ESTATE, "model not set for this pass");
+    if (n == 0) return RAISR_HIP_OK;
+    if (n > 0x7fffffffu / 3) return fail(RAISR_HIP_EINVAL, "too many triples");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 3 * sizeof(float)));
+    if (hipMalloc((void**)&d_out, n) != hipSuccess) { (void)hipFree(d_in); return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+    int rc = RAISR_HIP_OK;
+    PassParams P = make_pass(c, pass_index, 0, 0);
+    if (hipMemcpy(d_in, abd, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipDeviceSynchronize");
+    if (!rc) {
+        hipLaunchKernelGGL(k_debug_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, (unsigned)n, P,
+                           hash_flavour == RAISR_HIP_HASH_AVX2 ? 1 : 0, d_out);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_hash");
+    }
+    if (!rc && hipMemcpy(hash_out, d_out, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
+
+// Enable/disable per-kernel HIP-event timing of subsequent process calls (events are recorded on the
+// stream each kernel is launched on).
+int raisr_hip_kernel_timing_enable(raisr_hip_ctx* c, int on)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    KernelTimer& T = c->timer;
+    T.recs.clear(); T.names.clear();
+    if (on && T.pool.empty()) {
+        HIP_TRY(hipSetDevice(c->device));
+        T.pool.resize(2 * T.cap);
+        for (auto& e : T.pool) HIP_TRY(hipEventCreate(&e));
+    }
+    T.enabled = on != 0;
+    return RAISR_HIP_OK;
+}
+
+// Collects the timings recorded since the last enable: per kernel name, total milliseconds and
+// launch count.  Caller must have synchronised the stream(s).  Returns the number of kernels.
+int raisr_hip_kernel_timing_read(raisr_hip_ctx* c, char* names_out, float* total_ms_out, int* count_out, int max_kernels)
+{
+    if (!c || !names_out || !total_ms_out || !count_out) return fail(RAISR_HIP_EINVAL, "null argument");
+    KernelTimer& T = c->timer;
+    const int n = (int)T.names.size() < max_kernels ? (int)T.names.size() : max_kernels;
+    for (int i = 0; i < n; i++) {
+        snprintf(names_out + 64 * i, 64, "%s", T.names[i].c_str());
+        total_ms_out[i] = 0.f; count_out[i] = 0;
+    }
+    for (auto& r : T.recs) {
+        if (r.id >= n) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms_out[r.id] += ms; count_out[r.id]++; }
+    }
+    return n;
+}
+
+int raisr_hip_profile_kernels(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch,
+                              int iters, char* names_out, float* ms_out, int max_kernels)
+{
+    if (!c || iters <= 0 || !names_out || !ms_out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    int rc = raisr_hip_kernel_timing_enable(c, 1);
+    if (rc) return rc;
+    for (int i = 0; i < iters; i++) {
+        rc = raisr_hip_process_y_device(c, d_in, in_pitch, d_out, out_pitch, nullptr);
+        if (rc) return rc;
+    }
+    rc = raisr_hip_synchronize(c);
+    if (rc) return rc;
+    std::vector<int> counts(max_kernels);
+    int n = raisr_hip_kernel_timing_read(c, names_out, ms_out, counts.data(), max_kernels);
+    for (int i = 0; i < n; i++) if (counts[i]) ms_out[i] /= counts[i];
+    raisr_hip_kernel_timing_enable(c, 0);
+    return n;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,137 @@
+// kernels_common.h -- constants, per-pass parameters, XCD-aware tile order, LDS barrier, tile staging
+// Included by device_abi.hip inside its anonymous namespace, in the order given there (gfx950 only; built with
+// -ffp-contract=off and without fast-math: every floating-point operation is ONE IEEE operation of the cited reference line).
+#pragma once
+
+constexpr int kTaps = 121;
+constexpr int kTapsPad = 128;
+constexpr int kMargin = 6;       // gLoopMargin, Raisr.cpp:1574
+constexpr int kBlobHeader = 64;  // bytes
+
+struct GaussW {
+    float wT[11][12];            // wT[k][i] = weight of patch row i, column k (column-major for the k-outer loop)
+};
+
+struct PassParams {
+    int W, H;                    // plane size of this pass
+    int lr_pitch;                // LR plane pitch in u16 elements
+    int hash_pitch;              // hash plane pitch in bytes (u8 elements)
+    int hr_pitch;                // HR plane pitch in floats
+    float lo, hi;                // accept-test / clamp limits as float
+    int ilo, ihi;
+    int a_begin, a_end;          // columns hashed with the AVX-512 flavour
+    int b_begin, b_end;          // columns hashed with the AVX2 flavour (after the AVX-512 one)
+    int c_final;                 // first column that is never filtered
+    int ov_begin, ov_end;        // columns hashed twice (AVX-512 flavour, then AVX2): second hash lives in hash2
+    const uint8_t* hash2;        // [H][16] second hash of the overlap columns (column c -> c - ov_begin)
+    int pixel_types;             // 4 (ratio 2) or 1
+    int randomness;              // 1: BlendingMode Randomness (tail re-hash candidate replaces, never keeps, the first)
+    float qangle, qs0, qs1, qc0, qc1;
+    const float* bank;           // [hash][type][128]
+    int bank_bytes;              // size of the fp32 bank (buffer-descriptor range)
+    const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
+    const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
+    int write_hash;              // fused kernel: also write the hash plane (introspection for tests)
+    unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels} or null
+    int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
+    int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
+    const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
+};
+
+// XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
+// each XCD has a private 4 MiB L2, so with the plain (blockIdx.x, blockIdx.y) order the eight tiles around
+// any tile live in eight different L2s and every halo row/column is fetched from HBM again.  Remap the
+// dispatch index so that each XCD walks one contiguous row-major strip of tiles: neighbouring tiles then
+// share an L2 and the halo re-reads hit it.  Pure performance: any placement gives the same result.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by)
+{
+    const unsigned gx = gridDim.x, n = gridDim.x * gridDim.y;
+    const unsigned b = blockIdx.y * gx + blockIdx.x;
+    const unsigned n8 = n & ~7u;
+    const unsigned t = b < n8 ? (b & 7u) * (n8 >> 3) + (b >> 3) : b;
+    by = (int)(t / gx);
+    bx = (int)(t - (unsigned)by * gx);
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on
+// gfx950 the fence makes every wave wait for ALL its outstanding global loads and stores (s_waitcnt vmcnt(0)) -- which
+// turns a register prefetch of the next tile into a stall, and makes a persistent workgroup wait for the write
+// acknowledgement of its output stores at every tile.  The kernels below exchange nothing through global memory inside a
+// workgroup, so they wait for their LDS traffic only.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage an LH x LWLOAD window of a plane -- origin (y0, x0), replicate-clamped to the W x H plane --
+// into an LDS tile of row stride LSTRIDE, converting each sample to TL.  Block = 256 threads, linear sweep
+// (every lane busy).  All of a thread's global loads are issued before the first one is consumed: the
+// rolled form waited for each load in turn, i.e. ~9 dependent memory round trips at the head of every
+// workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int LH, int LWLOAD, typename T>
+struct TileRegs {
+    static constexpr int REM = LWLOAD - 64;                    // halo columns right of the first 64
+    static constexpr int NM = (LH + 3) / 4;                    // rows per wave in the main part
+    static constexpr unsigned NR = LH * REM, NRL = (NR + 255u) / 256u;
+    T vm[NM];
+    T vr[NRL];
+};
+
+// global -> registers half of stage_tile (all loads in flight, nothing waits): lets a persistent workgroup fetch the
+// next tile while it computes the current one
+template <int LH, int LWLOAD, typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TileRegs<LH, LWLOAD, T>& R)
+{
+    static_assert(LWLOAD > 64 && LWLOAD <= 128, "a tile row is one 64-lane sweep plus a remainder");
+    using TR = TileRegs<LH, LWLOAD, T>;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the row arithmetic stays scalar
+    __builtin_assume(w >= 0 && w < 4);
+    // main part: wave w sweeps columns [0,64) of rows w, w+4, ...: one clamped column index per lane for all rows
+    const int gxm = min(max(x0 + lane, 0), W - 1);
+#pragma unroll
+    for (int it = 0; it < TR::NM; it++) {
+        const int gy = min(max(y0 + min(w + 4 * it, LH - 1), 0), H - 1);
+        R.vm[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gxm];          // planes are < 2^31 samples: 32-bit offsets
+    }
+    // remainder: the REM right-hand columns of all rows, spread linearly over the block
+#pragma unroll
+    for (unsigned it = 0; it < TR::NRL; it++) {
+        const unsigned idx = min(threadIdx.x + 256u * it, TR::NR - 1u);
+        const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
+        const int gy = min(max(y0 + ty, 0), H - 1), gx = min(max(x0 + tx, 0), W - 1);
+        R.vr[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gx];
+    }
+}
+
+// registers -> LDS half (converting each sample to TL)
+template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
+__device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL* sL)
+{
+    using TR = TileRegs<LH, LWLOAD, T>;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(w >= 0 && w < 4);
+#pragma unroll
+    for (int it = 0; it < TR::NM; it++) {
+        const int ty = w + 4 * it;
+        if (ty < LH) sL[ty * LSTRIDE + lane] = (TL)(float)R.vm[it];
+    }
+#pragma unroll
+    for (unsigned it = 0; it < TR::NRL; it++) {
+        const unsigned idx = threadIdx.x + 256u * it;
+        const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
+        if (idx < TR::NR) sL[ty * LSTRIDE + tx] = (TL)(float)R.vr[it];
+    }
+}
+
+template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
+{
+    TileRegs<LH, LWLOAD, T> R;
+    load_tile<LH, LWLOAD>(src, pitch, W, H, y0, x0, R);
+    store_tile<LH, LWLOAD, LSTRIDE>(R, sL);
+}
+

@@ -1,0 +1,284 @@
+// kernels_filter.h -- 121-tap filter stage (filter_phase), k_filter, and the fused tile kernels k_hashfilter / k_hashfilter_ac (production)
+// Included by device_abi.hip inside its anonymous namespace, in the order given there (gfx950 only; built with
+// -ffp-contract=off and without fast-math: every floating-point operation is ONE IEEE operation of the cited reference line).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// k_filter: HR = (lo < v < hi) ? v : LR with v = DotProdPatch(patch, bank[hash][type])
+// (Raisr_AVX512.cpp:134-149; accept test Raisr.cpp:1196-1200).  16 lanes per pixel: lane l owns the
+// reference's zmm lane l: acc = p[l]*f[l]; acc = fma(p[16c+l], f[16c+l], acc) for c=1..7;
+// then sumitup_ps_512 as DPP row rotations by 8, 4, 2, 1.
+// Tile = 64 columns x 16 rows; wave w owns tile rows [4w, 4w+4); each step handles 4 adjacent pixels.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v)      // DPP quad_perm: CTRL = a | b<<2 | c<<4 | d<<6, lane i of a quad reads lane CTRL_i
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float tree16(float acc)
+{
+    acc = acc + row_ror<0x128>(acc);    // row_ror:8  -> r8[i] = a[i] + a[i+8]
+    acc = acc + row_ror<0x124>(acc);    // row_ror:4  -> r4[i] = r8[i] + r8[i+4]
+    acc = acc + row_ror<0x122>(acc);    // row_ror:2  -> r2[i] = r4[i] + r4[i+2]
+    acc = acc + row_ror<0x121>(acc);    // row_ror:1  -> r2[0] + r2[1]
+    return acc;
+}
+
+// filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
+// (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
+template <int LW>
+__device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
+                                             int c0, int r0, float* __restrict__ hr)
+{
+    constexpr int TW = 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, l = lane & 15;
+    int off[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) {
+        const int k = 16 * ch + l;
+        off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
+#ifdef RAISR_EXP_OCC4
+        asm volatile("" : "+v"(off[ch]));                      // one register per tap: left alone, the compiler keeps row and column part apart (16 VGPRs)
+#endif
+    }
+
+    // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
+    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P.bank), 0, P.bank_bytes, 0x00020000);
+    const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
+    const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
+    const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
+
+#pragma unroll 1
+    for (int row = 0; row < 4; row++) {
+        const int prow = 4 * w + row;
+        const int r = r0 + prow;
+        const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kTapsPad * 4) : 0u;
+        const unsigned row_lane_off = trow_off + lane_off;
+        // LDS byte addresses of this lane's 8 taps (and the centre pixel) for step 0; step s adds the immediate 16*s
+        const char* tap[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off[ch]);
+        const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
+#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
+#define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
+        float keep = 0.0f;
+        const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
+        // The 16 steps (4 adjacent pixels each) go in four groups {j, j+4, j+8, j+12}: the lane that keeps step s is
+        // l == s, so the four steps of a group end in four different quads of the pixel's 16 lanes.  Each step's
+        // accumulator is folded by the first two tree levels (row_ror 8, 4: every lane then holds r4[l & 3]), the four
+        // steps are merged quad-wise into one register (quad m <- step j+4m), and the last two levels, the accept
+        // test and the keep-select run once per group instead of once per step.  Same additions, same order.
+        const char* ctrq = ctr + 64 * (l >> 2);                // centre pixel of the step this lane's quad ends up with
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float part[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int s = j + 4 * m;
+                const unsigned hA = sH[prow * TW + 4 * s + g];
+                // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
+                // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
+                const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
+                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
+                part[m] = acc + row_ror<0x124>(acc);           // r4[i] = r8[i] + r8[i+4]   (period 4 over the 16 lanes)
+            }
+            float v = part[0];
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[3]), "s"(0xf000f000f000f000ull));
+            v = v + quad_perm<0x4e>(v);                        // [2,3,0,1]: r2 = r4[i] + r4[i+2]
+            v = v + quad_perm<0xb1>(v);                        // [1,0,3,2]: r2[0] + r2[1]
+            float res = RAISR_LDS_F(ctrq, j);
+            if (v > P.lo && v < P.hi) res = v;
+            // lane (g,l) keeps pixel column 4l+g, i.e. step l: in group j those are the lanes with (l & 3) == j
+            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
+        }
+        if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
+#pragma unroll 1                                                 //  Randomness blends the last candidate instead)
+            for (int s = 0; s < 16; s++) {
+                const unsigned hB = sH2[prow * TW + 4 * s + g];
+                if (hB == 0xFFu) continue;
+                const unsigned voff = __umul24(hB, bank_stride) + row_lane_off;
+                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                const float v = tree16(acc);
+                if (s == l) {
+                    if (v > P.lo && v < P.hi) keep = v;
+                    else if (P.randomness) keep = RAISR_LDS_F(ctr, s);
+                }
+            }
+        }
+#undef RAISR_LDS_F
+#undef RAISR_BANK_F
+        const int c = c0 + 4 * l + g;
+        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter(const T* __restrict__ lr, const uint8_t* __restrict__ hash,
+                                                PassParams P, float* __restrict__ hr, unsigned* __restrict__ fix_counters = nullptr)
+{
+    // split pipeline: this launch follows the fix kernels in stream order, so their list counters can be cleared here
+    if (fix_counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fix_counters[0] = 0;
+    constexpr int TW = 64, TH = 16, LW = TW + 11, LH = TH + 10;   // odd stride: fewer LDS bank conflicts on the patch reads
+    __shared__ float sL[LH * LW];
+    __shared__ uint8_t sH[TH * TW];         // first hash (0xFF = not filtered)
+    __shared__ uint8_t sH2[TH * TW];        // second hash of the overlap columns (0xFF elsewhere)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    stage_tile<LH, TW + 10, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 5, c0 - 5, sL);
+    for (int ty = w; ty < TH; ty += 4) {
+        const int r = r0 + ty, c = c0 + lane;
+        const bool in = r < P.H - kMargin && c < P.c_final;
+        sH[ty * TW + lane] = in ? hash[(size_t)r * P.hash_pitch + c] : (uint8_t)0xFFu;
+        sH2[ty * TW + lane] = (in && c >= P.ov_begin && c < P.ov_end) ? P.hash2[(size_t)r * 16 + (c - P.ov_begin)] : (uint8_t)0xFFu;
+    }
+    __syncthreads();
+    filter_phase<LW>(P, sL, sH, sH2, c0, r0, hr);
+}
+
+// k_hashfilter: both stages of a 64 x 16 tile in one kernel.  The tensor/hash stage is fp32-VALU bound and the
+// filter stage vector-L1 bound; with workgroups of one kernel in different stages on the same CU the two
+// resources are busy at the same time, which separate launches only achieve by accident across streams.
+// One LR window (6-px halo, stride 77: odd for the filter's patch reads) serves both stages; the hashes go from
+// registers to LDS, and to the hash plane only when a test asks for it.
+template <typename T, bool AVX2ALL>
+__global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr, PassParams P, GaussW gw,
+                                                       uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+{
+    constexpr int R = 4, TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12;
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[(TH + 10) * 74];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
+    __shared__ uint8_t sH[TH * TW];          // first hash; rows [4w, 4w+4) are written AND read by wave w only
+    __shared__ uint8_t sH2[TH * TW];         // AVX2 re-hash of the overlap columns
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+    stage_hash_tables<AVX2ALL>(P, sTab, sLut);
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    unsigned hA[R], hB[R];
+    hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
+    // A wave filters exactly the rows it hashed (rows [4w, 4w+4)), so no workgroup barrier separates the stages: the
+    // four waves of a tile drift apart and the VALU-bound and the L1-bound stage overlap inside the workgroup too.
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        sH[(w * R + j) * TW + lane] = (uint8_t)hA[j];
+        sH2[(w * R + j) * TW + lane] = (uint8_t)hB[j];
+        const int r = r0 + w * R + j;
+        if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
+    }
+    __builtin_amdgcn_wave_barrier();                         // LDS is in order within a wave; keep the compiler from reordering
+    filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
+}
+
+
+// k_hashfilter_ac: k_hashfilter with the certified hash stage (hash_phase_ac) -- the production kernel of the fp32
+// numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
+// pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
+// PART (profiling aid, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only (bucket 0).
+#ifdef RAISR_EXP_OCC4
+#define RAISR_AC_WGS 4
+#else
+#define RAISR_AC_WGS 3
+#endif
+template <typename T, int PART = 0>
+__global__ __launch_bounds__(256, RAISR_AC_WGS) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
+    __shared__ float sL[LH * LW];
+    using GT = typename GradOf<T>::type;
+    __shared__ GT sG[GH * GW_];
+    __shared__ float4 sV[3 * 4 * GW_];
+#ifdef RAISR_EXP_OCC4
+    uint2* sTab = reinterpret_cast<uint2*>(sV);   // the exact path's table takes sV's place once the H pass is done (hash_phase_ac)
+#else
+    __shared__ uint2 sTab[128];
+#endif
+    __shared__ uint8_t sH[TH * TW];
+    __shared__ uint8_t sH2[TH * TW];
+    __shared__ uint16_t sList[kListMax];      // worklist entries
+    __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+
+#ifndef RAISR_EXP_OCC4
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+#endif
+    if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
+            const unsigned idx = threadIdx.x + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
+    }
+    __syncthreads();
+    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0);
+    else {
+        // P.cert_check doubles as the bucket pattern of this profiling aid: 0 = every row of the bank, 1 = one row, 2 = sixteen rows
+        for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
+        __syncthreads();
+    }
+    if (P.write_hash) {
+        const int c = c0 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = r0 + 4 * w + j;
+            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
+        }
+    }
+    if (P.cert_stats && threadIdx.x == 0) {
+        const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
+        if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
+        if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
+        atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
+    }
+    if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
+    else if (sH[threadIdx.x] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+}
+
+

@@ -1,6 +1,6 @@
-// raisr_fp16_kernels.h -- gfx950 kernels reproducing the reference's AVX512-FP16 pipeline
+// kernels_fp16.h -- gfx950 kernels reproducing the reference's AVX512-FP16 pipeline
 // (ASMType AVX512_FP16; Library/Raisr_AVX512FP16.cpp) in IEEE binary16 arithmetic.
-// Included by raisr_kernels.hip inside its anonymous namespace (after PassParams).
+// Included by device_abi.hip inside its anonymous namespace (after kernels_hash_certify.h).
 //
 // Every arithmetic statement below is ONE binary16 operation with round-to-nearest-even and
 // subnormals preserved (v_*_f16 / v_pk_*_f16 under the default gfx9 float mode), in the order of the

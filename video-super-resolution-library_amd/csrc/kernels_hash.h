@@ -1,0 +1,365 @@
+// kernels_hash.h -- the reference's hash per pixel and the all-exact structure-tensor stage: hash_px_*, hash_phase, k_hash (+ the k_debug_hash test hook)
+// Included by device_abi.hip inside its anonymous namespace, in the order given there (gfx950 only; built with
+// -ffp-contract=off and without fast-math: every floating-point operation is ONE IEEE operation of the cited reference line).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// hash (per pixel), strict operation order of GetHashValue_AVX512_32f_16Elements
+// (Raisr_AVX512.cpp:175-258) / GetHashValue_AVX256_32f_8Elements (Raisr_AVX256.cpp:393-472)
+// ------------------------------------------------------------------------------------------------
+// sqrt14(v) = VRCP14(VRSQRT14(v)).  Branch-free for everything the hash actually produces:
+//   v normal, positive, finite -> both table evaluations stay in the normal range (the rsqrt14 result
+//                                 has a biased exponent in [62,190]);
+//   v == +-0                   -> rcp14(+-inf) = +-0;
+//   v negative (not NaN)       -> rsqrt14 gives the QNaN indefinite, rcp14 passes it through.
+// Positive denormals, +inf and NaN inputs (never produced by 8/10-bit content) take the
+// generic models of x86_approx_dev.h behind a rarely-taken branch.
+// Fully branch-free: inputs outside the three cases above set `rare` and the caller recomputes that
+// pixel with the generic models (x86_approx_dev.h) -- so the hashes of a lane's pixels are straight-line
+// code the scheduler can interleave.
+__device__ __forceinline__ float sqrt14_fast(float v, const uint2* tab, bool& rare)
+{
+    const uint32_t x = __float_as_uint(v);
+    // rsqrt14 table row = [exponent parity p][top 5 mantissa bits] = bits 23..18 of x with bit 23 inverted
+    // (p = (E-127)&1 = ~E&1); every bit pattern yields an in-range row, so nothing has to be sanitised first
+    uint2 c = tab[64u + (((x >> 18) & 63u) ^ 32u)];
+    uint32_t code = (c.x - __umul24(c.y, (x >> 8) & 1023u)) >> 9;          // rsqrt14 mantissa code (16 bits); C1*t < 2^26
+    const bool pow4 = (x & 0x00ffffffu) == 0x00800000u;                     // p == 0 && m == 0: exact power of four
+    code = pow4 ? 0u : code;
+    // rcp14 of the (normal) intermediate y = 2^(-half-1) * (1 + code/65536)  [or 2^-half when pow4]:
+    // its top 6 / next 10 mantissa bits are code>>10 / code&1023, so y never has to be assembled
+    c = tab[code >> 10];
+    uint32_t code2 = (c.x - __umul24(c.y, code & 1023u)) >> 9;
+    asm volatile("" : "+v"(code2));     // keep the second look-up unconditional: a branch around it would serialise the lane's 12 roots
+    const uint32_t ez = ((x + 0x3f800000u) >> 1) & 0x7f800000u;             // biased exponent (E+127)>>1 of the root
+    // y an exact power of two (code == 0): rcp14 is exact as well -- 2^half for a power of four, else one binade up
+    const uint32_t zp = ez + (pow4 ? 0u : 0x00800000u);
+    uint32_t z = (code == 0u) ? zp : (ez | (code2 << 7));
+    const bool normal = __builtin_amdgcn_classf(v, 0x100);               // +normal
+    const bool zero = __builtin_amdgcn_classf(v, 0x060);                 // +-0 -> rcp14(+-inf) = +-0
+    // -inf, -normal, -denormal -> QNaN indefinite; sNaN, qNaN, +denormal, +inf -> generic model (caller)
+    z = normal ? z : (zero ? x : 0xffc00000u);
+    rare |= __builtin_amdgcn_classf(v, 0x283);
+    return __uint_as_float(z);
+}
+
+// RCPPS(RSQRTPS(v)), branch-free (the composition of x86dev::rsqrt_legacy and x86dev::rcp_legacy):
+//   +normal: y = RSQRTPS(v) has exponent 126-half and the 12-bit mantissa code q = lut[2048 + 1024p + (m>>13)];
+//            RCPPS(y) looks up y's top 11 mantissa bits (= q>>1): exponent 253-(126-half) = (E+127)>>1, mantissa lut[q>>1]<<11;
+//   +-0 and +-denormal (DAZ) -> RSQRTPS = +-inf -> RCPPS = +-0;   -normal, -inf -> QNaN indefinite;
+//   +inf -> RSQRTPS = +0 -> RCPPS = +inf;   NaN -> quieted NaN.
+__device__ __forceinline__ float sqrt_legacy_fast(float v, const uint16_t* lut)
+{
+    const uint32_t x = __float_as_uint(v);
+    const uint32_t q = lut[2048u + (((x >> 13) & 2047u) ^ 1024u)];          // [p = ~E&1][m>>13]: bits 23..13, bit 23 inverted
+    const uint32_t r = lut[q >> 1];
+    const uint32_t ez = ((x + 0x3f800000u) >> 1) & 0x7f800000u;             // biased exponent (E+127)>>1 of the root
+    uint32_t z = ez | (r << 11);
+    const bool normal = __builtin_amdgcn_classf(v, 0x100);
+    const bool tiny = __builtin_amdgcn_classf(v, 0x0f0);                    // +-0, +-denormal
+    const bool negative = __builtin_amdgcn_classf(v, 0x00c);                // -inf, -normal
+    const bool nan = __builtin_amdgcn_classf(v, 0x003);
+    uint32_t sp = nan ? (x | 0x00400000u) : x;                              // NaN quieted; +inf stays +inf
+    sp = negative ? 0xffc00000u : sp;
+    sp = tiny ? (x & 0x80000000u) : sp;
+    z = normal ? z : sp;
+    return __uint_as_float(z);
+}
+
+// Hash thresholds, passed BY VALUE (SGPRs): taking PassParams by reference in an out-of-line function would
+// force the whole struct into scratch memory.
+struct HashQ { float qangle, qs0, qs1, qc0, qc1; const uint16_t* lut; };
+
+// MODE 0: AVX-512 flavour, branch-free fast path (sets `rare` when the generic model is needed);
+// MODE 1: AVX2 flavour (legacy LUT instructions); MODE 2: AVX-512 flavour, generic models.
+template <int MODE>
+__device__ __forceinline__ float sqrt_approx(float v, const uint2* tab, const uint16_t* lut, bool& rare)
+{
+    if (MODE == 1) return sqrt_legacy_fast(v, lut);
+    if (MODE == 2) return x86dev::rcp14(x86dev::rsqrt14(v, tab + 64), tab);
+    return sqrt14_fast(v, tab, rare);
+}
+
+template <int MODE>
+__device__ __forceinline__ int hash_px_impl(float a, float b, float d, const HashQ P, const uint2* tab, bool& rare)
+{
+    constexpr bool LEGACY = MODE == 1;
+    const float pi = 3.141592653f;                       // Raisr_globals.h:29
+    const float T = a + d;
+    const float Dt = (a * d) - (b * b);
+    const float rad = ((T * T) * 0.25f) - Dt;            // x/4 == x*0.25 exactly
+    const float s = sqrt_approx<MODE>(rad, tab, P.lut, rare);
+    const float hT = T * 0.5f;                           // T/2
+    const float L1 = hT + s;
+    const float L2 = hT - s;
+    const float xx = (b < 0.0f || b > 0.0f) ? (L1 - d) : 1.0f;   // _CMP_NEQ_OQ
+    // atan2Approximation (Raisr_AVX512.cpp:151-173)
+    const float ONEQTR_PI = (float)(3.14159265358979323846 / 4.0);          // (float)(M_PI/4.0)
+    const float THRQTR_PI = (float)(3.0 * 3.14159265358979323846 / 4.0);    // (float)(3.0*M_PI/4.0)
+    const float ay = __builtin_fabsf(b) + 1e-10f;
+    // r = x<0 ? (x+|y|)/(|y|-x) : (x-|y|)/(x+|y|): select the operands, divide once (same IEEE op)
+    const bool neg = xx < 0.0f;
+    const float xpa = xx + ay;
+    const float num = neg ? xpa : (xx - ay);
+    const float den = neg ? (ay - xx) : xpa;
+    const float rr = num / den;
+    float ang = neg ? THRQTR_PI : ONEQTR_PI;
+    ang = __builtin_fmaf(__builtin_fmaf(0.1963f * rr, rr, -0.9817f), rr, ang);
+    const float nang = -1.0f * ang;
+    ang = (b < 0.0f) ? nang : ang;
+    ang = ang + ((ang < 0.0f) ? pi : 0.0f);
+    const float sL1 = sqrt_approx<MODE>(L1, tab, P.lut, rare);
+    const float sL2 = sqrt_approx<MODE>(L2, tab, P.lut, rare);
+    const float coh = (sL1 - sL2) / ((sL1 + sL2) + 1e-17f);
+    const float str = L1;
+    const float fl = __builtin_floorf(ang * P.qangle);
+    int ai = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;   // cvtps_epi32
+    ai = min(23, max(ai, 0));
+    int si, ci;
+    if (!LEGACY) {
+        si = (int)(P.qs0 <= str) + (int)(P.qs1 <= str);
+        ci = (int)(P.qc0 <= coh) + (int)(P.qc1 <= coh);
+    } else {
+        si = 2 - ((int)(str <= P.qs0) + (int)(str <= P.qs1));
+        ci = 2 - ((int)(coh <= P.qc0) + (int)(coh <= P.qc1));
+    }
+    return ai * 9 + si * 3 + ci;
+}
+
+// out-of-line slow paths (kept out of the hot straight-line code)
+__device__ __attribute__((noinline)) int hash_px_generic(float a, float b, float d, const HashQ P, const uint2* tab)
+{
+    bool unused = false;
+    return hash_px_impl<2>(a, b, d, P, tab, unused);
+}
+__device__ __attribute__((noinline)) int hash_px_legacy(float a, float b, float d, const HashQ P, const uint2* tab)
+{
+    bool unused = false;
+    return hash_px_impl<1>(a, b, d, P, tab, unused);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash: structure tensor + hash.  Block = 256 threads = 4 waves; tile = 64 columns x 4R rows of
+// the filtered zone [6,H-6) x [6,c_final); wave w owns rows [wR, wR+R), lane = column.
+// Column accumulators S_k (k = patch column) are built sequentially over the 11 patch rows
+// (computeGTWG_Segment_AVX512_32f, Raisr_AVX512.cpp:96-121) and folded in the association of
+// sumitup_ps_512 (:37-44): sum = ((S1+S9)+S5 + (S7+S3)) + (((S0+S8)+S4) + ((S2+S10)+S6)).
+// (The even/odd-pixel lane placements of the reference give the same value: they only commute
+// operands of individual additions.)
+// ------------------------------------------------------------------------------------------------
+__constant__ int c_col_order[11] = {0, 8, 4, 2, 10, 6, 1, 9, 5, 7, 3};
+
+// Gradient tile element (gx, gy).  (A binary16-packed tile -- 8-bit gradients are exact in binary16 and v_fma_mix_f32 gives
+// the products directly -- halves the tile's LDS, but measured 3 % slower in k_hashfilter_ac and no faster in k_hash_ac.)
+__device__ __forceinline__ f2 grad_load(const f2* p) { return *p; }
+__device__ __forceinline__ void grad_store(f2* p, float gx, float gy) { *p = (f2){gx, gy}; }
+__device__ __forceinline__ void grad_products(const f2* p, float& pa, float& pb, float& pd)
+{
+    const f2 g = *p;
+    pa = g.x * g.x; pb = g.x * g.y; pd = g.y * g.y;
+}
+template <typename T> struct GradOf { using type = f2; };
+
+
+
+// AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
+// LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
+//
+// hash_phase: the work of one tile once its LR window (origin (r0-6, c0-6), row stride LW) is in sL.  Returns, per
+// lane (= column c0+lane) and row j of the wave's R rows, hA = first hash (0xFF: pixel not filtered) and hB = the
+// AVX2 re-hash of an overlap column (0xFF elsewhere).  Ends with every wave past its last LDS read of sG.
+template <int R, bool AVX2ALL, int LW, typename GT = f2>
+__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, GT* sG,
+                                           const uint2* sTab, const uint16_t* sLut, int c0, int r0,
+                                           unsigned (&hA)[R], unsigned (&hB)[R])
+{
+    constexpr int TH = 4 * R;
+    constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+    {
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
+            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)                                       // columns [0,64): wave = row
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {                           // the 10 right-hand columns
+            const unsigned idx = threadIdx.x + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
+    }
+    __syncthreads();
+
+    f2 curAD[R], holdAD[R], t1AD[R];
+    float curB[R], holdB[R], t1B[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        curAD[j] = holdAD[j] = t1AD[j] = (f2){0.f, 0.f};
+        curB[j] = holdB[j] = t1B[j] = 0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < 11; kk++) {
+        const int k = c_col_order[kk];
+        f2 g[R + 10];
+#pragma unroll
+        for (int t = 0; t < R + 10; t++) g[t] = grad_load(&sG[(w * R + t) * GW_ + lane + k]);
+        f2 AD[R];
+        float B[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) { AD[j] = (f2){0.f, 0.f}; B[j] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float wv = gw.wT[k][i];
+            const f2 w2 = {wv, wv};
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const f2 gg = g[i + j];
+                const f2 pq = gg * w2;                                   // (gx*w, gy*w)
+                AD[j] = __builtin_elementwise_fma(pq, gg, AD[j]);        // A += (gx*w)*gx ; D += (gy*w)*gy
+                B[j] = __builtin_fmaf(pq.x, gg.y, B[j]);                 // B += (gx*w)*gy
+            }
+        }
+        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
+        if (start) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = AD[j]; curB[j] = B[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) { curAD[j] = curAD[j] + AD[j]; curB[j] = curB[j] + B[j]; }
+        }
+        if (kk == 2 || kk == 8) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { holdAD[j] = curAD[j]; holdB[j] = curB[j]; }
+        }
+        if (kk == 5) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { t1AD[j] = holdAD[j] + curAD[j]; t1B[j] = holdB[j] + curB[j]; }
+        }
+    }
+
+    const int c = c0 + lane;
+    f2 ad[R];
+    float bb[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        ad[j] = (holdAD[j] + curAD[j]) + t1AD[j];            // (Gb+Gc) + (Ga+Gd)
+        bb[j] = (holdB[j] + curB[j]) + t1B[j];
+    }
+    const bool inB = c >= P.b_begin && c < P.b_end;
+    if constexpr (AVX2ALL) {
+        const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, sLut};
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            bool unused = false;
+            const unsigned h = (unsigned)hash_px_impl<1>(ad[j].x, bb[j], ad[j].y, HQ, sTab, unused);
+            const int r = r0 + w * R + j;
+            hA[j] = (r < P.H - kMargin && c < P.c_final && inB) ? h : 0xFFu;
+            hB[j] = 0xFFu;
+        }
+        return;
+    }
+    // AVX-512 flavour for every pixel of the lane as straight-line code (independent chains interleave);
+    // the rare cases -- generic approximation-instruction inputs, AVX2 flavour of the tail columns -- follow.
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const bool inA = c >= P.a_begin && c < P.a_end;
+    unsigned h1[R];
+    bool rare[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) { h1[j] = 0xFFu; rare[j] = false; }
+    if (P.a_end > P.a_begin) {                               // kernel-uniform
+#pragma unroll
+        for (int j = 0; j < R; j++) h1[j] = (unsigned)hash_px_impl<0>(ad[j].x, bb[j], ad[j].y, HQ, sTab, rare[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        hA[j] = 0xFFu; hB[j] = 0xFFu;
+        if (r < P.H - kMargin && c < P.c_final) {
+            unsigned h = h1[j];
+            if (rare[j]) h = (unsigned)hash_px_generic(ad[j].x, bb[j], ad[j].y, HQ, sTab);
+            if (inB) {                                       // the tail columns of AVX-512 mode
+                const unsigned hL = (unsigned)hash_px_legacy(ad[j].x, bb[j], ad[j].y, HQ, sTab);
+                if (inA) hB[j] = hL;                         // re-hashed tail column
+                else h = hL;
+            }
+            hA[j] = (inA || inB) ? h : 0xFFu;
+        }
+    }
+}
+
+// stage the approximation tables of the hash flavour into LDS
+template <bool AVX2ALL>
+__device__ __forceinline__ void stage_hash_tables(const PassParams& P, uint2* sTab, uint16_t* sLut)
+{
+    if constexpr (AVX2ALL) {
+        const uint2* src = reinterpret_cast<const uint2*>(P.lut_legacy);           // 4096 x u16 = 1024 x 8 B
+        for (int i = threadIdx.x; i < 1024; i += 256) reinterpret_cast<uint2*>(sLut)[i] = src[i];
+    } else {
+        if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    }
+}
+
+template <int R, typename T, bool AVX2ALL>
+__global__ __launch_bounds__(256, 4) void k_hash(const T* __restrict__ lr, PassParams P, GaussW gw,
+                                                  uint8_t* __restrict__ hash_out, uint8_t* __restrict__ hash2_out)
+{
+    constexpr int TH = 4 * R;
+    constexpr int LW = 76, LH = TH + 12;    // LR tile incl. 6-px halo
+    __shared__ float sL[LH * LW];
+    __shared__ f2 sG[(TH + 10) * 74];
+    __shared__ uint2 sTab[AVX2ALL ? 1 : 128];
+    __shared__ uint16_t sLut[AVX2ALL ? 4096 : 1];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
+
+    stage_hash_tables<AVX2ALL>(P, sTab, sLut);
+    stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    __syncthreads();
+    unsigned hA[R], hB[R];
+    hash_phase<R, AVX2ALL, LW>(P, gw, sL, sG, sTab, sLut, c0, r0, hA, hB);
+    const int c = c0 + lane;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int r = r0 + w * R + j;
+        if (r < P.H - kMargin && c < P.c_final) {
+            hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = (uint8_t)hA[j];
+            if (hB[j] != 0xFFu) hash2_out[(size_t)r * 16 + (c - P.ov_begin)] = (uint8_t)hB[j];
+        }
+    }
+}
+
+// Test hook: the fp32 hash of arbitrary (a, b, d) tensor triples through exactly the code k_hash runs
+// (fast path + generic fall-back for the AVX-512 flavour, or the AVX2 flavour).
+__global__ __launch_bounds__(256) void k_debug_hash(const float* __restrict__ abd, unsigned n, PassParams P, int legacy,
+                                                    uint8_t* __restrict__ out)
+{
+    __shared__ uint2 sTab[128];
+    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
+    __syncthreads();
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const float a = abd[3 * (size_t)i], b = abd[3 * (size_t)i + 1], d = abd[3 * (size_t)i + 2];
+    unsigned h;
+    if (legacy) {
+        h = (unsigned)hash_px_legacy(a, b, d, HQ, sTab);
+    } else {
+        bool rare = false;
+        h = (unsigned)hash_px_impl<0>(a, b, d, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px_generic(a, b, d, HQ, sTab);
+    }
+    out[i] = (uint8_t)h;
+}
+
+

@@ -1,0 +1,324 @@
+// kernels_hash_certify.h -- certified hashing: separable approximate tensor, approx_hash with its error bounds, exact 16-lane fallback, hash_phase_ac
+// Included by device_abi.hip inside its anonymous namespace, in the order given there (gfx950 only; built with
+// -ffp-contract=off and without fast-math: every floating-point operation is ONE IEEE operation of the cited reference line).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Certified hashing ("approximate, then certify").  The output needs the exact BUCKET, not the exact
+// tensor.  k_hashfilter_ac therefore computes the structure tensor cheaply -- the literal 11 x 11 table is a rank-1
+// table up to its 6-digit truncation, so a separable 11 + 11-tap pass over the per-pixel gradient products
+// (gx^2, gx gy, gy^2) reproduces (a, b, d) to a relative eps of a few 1e-6 -- evaluates the hash quantities in plain
+// fp32 (native sqrt / rcp), and accepts the bucket only when rigorous bounds on
+//     |quantity the reference's instruction sequence produces  -  quantity computed here|
+// keep angle*24/pi, strength and coherence away from every bucket boundary and every discontinuity of the
+// reference's code (sign of b, xx, L2, the "ang < 0" wrap).  Everything else -- a few per cent of the pixels on
+// noisy content, 1-D structures and exactly symmetric patterns on synthetic content -- goes through a per-tile
+// worklist to the exact code (exact_pixel below: the same operations in the same order as hash_phase).
+// The bounds (tests/tools/certify_proto.py derives and validates them against the oracle):
+//   tensor      |a-a'| <= eps a', |d-d'| <= eps d', |b-b'| <= eps T'/2,  T' = a'+d'
+//               eps = 1.05 (eps_w + 48 u): eps_w = max |us_i us_k / w_ik - 1| over the ACTUAL fp32 constants of both paths,
+//               16 u for the reference's 12-term fma chains + 4-level fold, 23 u for the separable passes (u = 2^-24).
+//   root        reference: rad = fl(T^2/4 - (ad - b^2)) = R + eta, R = ((a-d)/2)^2 + b^2, |eta| <= 2 u T^2;  s = sqrt14(rad),
+//               sqrt14(x) = sqrt(x)(1 + e), |e| <= E (1.0e-4 for VRCP14(VRSQRT14), 6.5e-4 for RCPPS(RSQRTPS); enumerated in
+//               tests/test_certify_bounds.py).  With s* = sqrt(R'):   |s - s*| <= E_s = 1.42 eps T' + (2e-7 + eps^2) T'^2 / s* + 1.05 E s*
+//   L1, L2, xx  |. - .*| <= E_L = E_s + (eps/2 + 6 u) T'   (L2* = (a'd' - b'^2) / L1* carries 4 u T' more)
+//   coherence   t = sqrt(L2/L1): |coh - coh*| <= 2 t* (0.55 (E_L2/(L2*-E_L2) + E_L/(L1*-E_L)) + 2.4 E) + 2e-6, needs L2* > 2 E_L2
+//   angle       rr = (xx - ay)/(xx + ay), |d rr| <= 2((ay+E_ay) E_L + (xx+E_L) E_ay) / (xx + ay - E_L - E_ay)^2 + 4 u,
+//               |P'(rr)| < 1 for the cubic P  =>  |ang_raw - ang_raw*| <= d rr + 1.5e-6;  q = ang 24/pi: + 2e-5
+// ------------------------------------------------------------------------------------------------
+struct SepW {
+    float us[11];                // separable weights, sqrt(NF) folded in: us[i] us[k] ~ wT[k][i]
+    float es1, es2;              // 1.42 eps, 2e-7 + eps^2
+    float eEL, eEb;              // eps/2 + 6 u, eps/2
+    float e105[2], e24[2];       // 1.05 E and 2.4 E for the AVX-512 (0) and the AVX2 (1) approximation instructions
+};
+
+struct HashQf { float qangle, qs0, qs1, qc0, qc1; };
+
+// returns true when the bucket is certified
+__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, unsigned& bucket)
+{
+    const float U1 = 5.9604645e-8f;                      // 2^-24
+    const float pi = 3.141592653f;
+    const float ONEQTR_PI = (float)(3.14159265358979323846 / 4.0);
+    const float T = a + d;
+    const float m = 0.5f * (a - d);
+    const float bb = b * b;
+    const float R = __builtin_fmaf(m, m, bb);
+    const float s = __builtin_amdgcn_sqrtf(R);
+    const float hT = 0.5f * T;
+    const float L1 = hT + s;
+    const float rL1 = __builtin_amdgcn_rcpf(L1);
+    const float det = __builtin_fmaf(a, d, -bb);
+    const float L2 = det * rL1;                          // = T/2 - s without the cancellation
+    const float rs = __builtin_amdgcn_rcpf(s);
+    const float E_s = __builtin_fmaf(S.es1, T, __builtin_fmaf((S.es2 * T) * T, rs, S.e105[fl] * s));
+    bool ok = (T > 0.0f) & (s > 0.0f) & (E_s <= 0.25f * s);
+    const float E_L = __builtin_fmaf(S.eEL, T, E_s);
+    const float E_L2 = __builtin_fmaf(4.0f * U1, T, E_L);
+    // strength
+    ok &= (__builtin_fabsf(L1 - Q.qs0) > E_L) & (__builtin_fabsf(L1 - Q.qs1) > E_L);
+    const int si = (int)(Q.qs0 <= L1) + (int)(Q.qs1 <= L1);
+    // coherence
+    ok &= L2 > 2.0f * E_L2;
+    const float t = __builtin_amdgcn_sqrtf(L2 * rL1);
+    const float coh = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    const float dcoh = __builtin_fmaf(2.0f * t, __builtin_fmaf(0.55f, __builtin_fmaf(E_L2, __builtin_amdgcn_rcpf(L2 - E_L2), E_L * __builtin_amdgcn_rcpf(L1 - E_L)), S.e24[fl]), 2e-6f);
+    ok &= (__builtin_fabsf(coh - Q.qc0) > dcoh) & (__builtin_fabsf(coh - Q.qc1) > dcoh);
+    const int ci = (int)(Q.qc0 <= coh) + (int)(Q.qc1 <= coh);
+    // angle
+    const float E_b = S.eEb * T;
+    const float ab = __builtin_fabsf(b);
+    const float ay = ab + 1e-10f;
+    const float xx = m >= 0.0f ? m + s : bb * __builtin_amdgcn_rcpf(s - m);        // (s - m)(s + m) = b^2
+    const float E_ay = __builtin_fmaf(U1, ay, E_b);
+    const float xpa = xx + ay;
+    const float D = xpa - (E_L + E_ay);
+    const float rr = (xx - ay) * __builtin_amdgcn_rcpf(xpa);
+    const float rD = __builtin_amdgcn_rcpf(D);
+    const float drr = __builtin_fmaf(2.0f * __builtin_fmaf(ay + E_ay, E_L, (xx + E_L) * E_ay), rD * rD, 4.0f * U1);
+    const float ang_raw = __builtin_fmaf(__builtin_fmaf(0.1963f * rr, rr, -0.9817f), rr, ONEQTR_PI);
+    const float dang = drr + 1.5e-6f;
+    float ang = b < 0.0f ? -ang_raw : ang_raw;
+    ang = ang < 0.0f ? ang + pi : ang;
+    const float q = ang * Q.qangle;
+    const float dq = __builtin_fmaf(Q.qangle, dang, 2e-5f);
+    const float k = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(q), 0.0f), 23.0f);
+    const float fr = q - k;
+    const bool c_ang = (xx > 2.0f * E_L) & (D > 0.0f) & (ab > E_b) & (__builtin_fabsf(ang_raw) > dang) &
+                       ((k < 1.0f) | (fr > dq)) & ((k > 22.0f) | (1.0f - fr > dq));
+    ok &= c_ang;                                         // (a window without any gx or gy has L2 = 0 and is never certified)
+    bucket = (unsigned)((int)k * 9 + si * 3 + ci);
+    return ok;
+}
+
+// first / second hash of a pixel in column c from its exact tensor: the flavour logic of hash_phase's epilogue
+__device__ __forceinline__ void flavour_hash(const PassParams& P, const uint2* sTab, float a, float b, float d, int c, unsigned& hA, unsigned& hB)
+{
+    const HashQ HQ = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1, P.lut_legacy};
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    hA = 0xFFu; hB = 0xFFu;
+    unsigned h = 0xFFu;
+    if (inA) {
+        bool rare = false;
+        h = (unsigned)hash_px_impl<0>(a, b, d, HQ, sTab, rare);
+        if (rare) h = (unsigned)hash_px_generic(a, b, d, HQ, sTab);
+    }
+    if (inB) {
+        const unsigned hL = (unsigned)hash_px_legacy(a, b, d, HQ, sTab);
+        if (inA) hB = hL; else h = hL;
+    }
+    hA = (inA || inB) ? h : 0xFFu;
+}
+
+// Exact tensor of up to four worklist pixels per wave with 16 lanes per pixel: lane l < 11 of a group runs the
+// reference's chain of patch column l (the 11 patch rows in order, weights wl[i] = wT[l][i]); the 11 column sums are
+// folded in sumitup_ps_512's association with DPP row shifts (row_shl:n -- lane i reads lane i+n of its row of 16):
+//   u = S + shl8(S): lanes 0..2 = S0+S8, S1+S9, S2+S10;  v = u + shl4(S): Ga, Gb, Gd;  lane 3: S3 + S7 = Gc;
+//   r = z + shl2(z): lane 0 = Ga+Gd, lane 1 = Gb+Gc;  lane 0: (Ga+Gd) + (Gb+Gc)  [fp addition commutes bit for bit].
+// The latency of one round is ~11 rows instead of 121 taps: what matters when only a handful of pixels per tile need it.
+template <int CTRL>
+__device__ __forceinline__ float row_shl(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fold11(float S, bool lane3)
+{
+    const float u = S + row_shl<0x108>(S);
+    const float v = u + row_shl<0x104>(S);
+    const float wv = S + row_shl<0x104>(S);
+    const float z = lane3 ? wv : v;
+    const float r = z + row_shl<0x102>(z);
+    return r + row_shl<0x101>(r);
+}
+template <typename GT>
+__device__ __forceinline__ void exact_tensor16(const GT* sG, const float (&wl)[11], int prow, int pcol, int l, float& a, float& b, float& d)
+{
+    constexpr int GW_ = 74;
+    const GT* base = sG + prow * GW_ + pcol + min(l, 10);
+    f2 AD = {0.f, 0.f};
+    float B = 0.f;
+    f2 gg[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) gg[i] = grad_load(base + i * GW_);
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        const f2 w2 = {wl[i], wl[i]};
+        const f2 pq = gg[i] * w2;
+        AD = __builtin_elementwise_fma(pq, gg[i], AD);
+        B = __builtin_fmaf(pq.x, gg[i].y, B);
+    }
+    const bool lane3 = l == 3;
+    a = fold11(AD.x, lane3);
+    b = fold11(B, lane3);
+    d = fold11(AD.y, lane3);
+}
+
+// Approximate structure tensor of the lane's 4 pixels (rows [4w, 4w+4) of the tile, column = lane): separable 11 + 11 taps
+// on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4),
+// results as float4 per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
+template <typename GT>
+__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4])
+{
+    constexpr int GW_ = 74;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto vpass = [&](int x, int rg) {
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 14; t++) {
+            float pa, pb, pd;
+            grad_products(sG + (4 * rg + t) * GW_ + x, pa, pb, pd);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = t - r;
+                if (i >= 0 && i < 11) {
+                    va[r] = __builtin_fmaf(S.us[i], pa, va[r]);
+                    vb[r] = __builtin_fmaf(S.us[i], pb, vb[r]);
+                    vd[r] = __builtin_fmaf(S.us[i], pd, vd[r]);
+                }
+            }
+        }
+        sV[(0 * 4 + rg) * GW_ + x] = make_float4(va[0], va[1], va[2], va[3]);
+        sV[(1 * 4 + rg) * GW_ + x] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        sV[(2 * 4 + rg) * GW_ + x] = make_float4(vd[0], vd[1], vd[2], vd[3]);
+    };
+    vpass(lane, w);
+    if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
+    // software-pipelined by hand (next column's three float4 in flight during this column's 12 FMAs) and fenced per
+    // column: left alone, the scheduler issues all 33 loads first and sinks the FMAs into the hash code -- 132 live VGPRs
+    float4 xa = sV[(0 * 4 + w) * GW_ + lane], xb = sV[(1 * 4 + w) * GW_ + lane], xd = sV[(2 * 4 + w) * GW_ + lane];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        float4 na = xa, nb = xb, nd = xd;
+        if (k < 10) {
+            na = sV[(0 * 4 + w) * GW_ + lane + k + 1];
+            nb = sV[(1 * 4 + w) * GW_ + lane + k + 1];
+            nd = sV[(2 * 4 + w) * GW_ + lane + k + 1];
+        }
+        const float uk = S.us[k];
+        ta[0] = __builtin_fmaf(uk, xa.x, ta[0]); ta[1] = __builtin_fmaf(uk, xa.y, ta[1]); ta[2] = __builtin_fmaf(uk, xa.z, ta[2]); ta[3] = __builtin_fmaf(uk, xa.w, ta[3]);
+        tb[0] = __builtin_fmaf(uk, xb.x, tb[0]); tb[1] = __builtin_fmaf(uk, xb.y, tb[1]); tb[2] = __builtin_fmaf(uk, xb.z, tb[2]); tb[3] = __builtin_fmaf(uk, xb.w, tb[3]);
+        td[0] = __builtin_fmaf(uk, xd.x, td[0]); td[1] = __builtin_fmaf(uk, xd.y, td[1]); td[2] = __builtin_fmaf(uk, xd.z, td[2]); td[3] = __builtin_fmaf(uk, xd.w, td[3]);
+        xa = na; xb = nb; xd = nd;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // pin the 12 sums here: otherwise LLVM sinks the FMAs of rows 1..3 into the per-pixel hash code and keeps (spills) the loaded columns
+#pragma unroll
+    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(ta[r]), "+v"(tb[r]), "+v"(td[r]));
+}
+
+// hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
+// (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
+constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilter_ac: more uncertain pixels -> the whole tile takes the exact routine
+template <int LW, typename GT>
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, float4* sV,
+                                              const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
+                                              int c0, int r0)
+{
+    constexpr int GW_ = 74, TW = 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCnt[0] = 0;
+    float ta[4], tb[4], td[4];
+    tensor_ac(S, sG, sV, ta, tb, td);
+    // ---- approximate hash + certification of the lane's 4 pixels ----
+    const int c = c0 + lane;
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    const int fl = inB ? 1 : 0;                            // the AVX2 flavour's wider table error covers the re-hashed columns too
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    unsigned nUnc = 0, certbits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int prow = 4 * w + j;
+        const int r = r0 + prow;
+        const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
+        unsigned bucket;
+        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket);
+        const bool zero = (ta[j] + td[j]) == 0.0f;          // flat window: the reference's tensor is exactly (0, 0, 0) as well
+        cert |= zero;
+        // first hash: AVX-512 flavour where the column has one, else the AVX2 flavour; second hash: AVX2 flavour of the
+        // re-hashed columns.  A certified bucket holds for both flavours (fl selects the wider table error there); the
+        // zero tensor's bucket is looked up per flavour (computed once per tile with the exact code).
+        const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
+        const unsigned bB = zero ? (unsigned)P.zero_bucket[1] : bucket;
+        const bool unc = zone && (!cert || P.cert_check);
+        sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
+        sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
+        certbits |= (cert ? 1u : 0u) << j;
+        if (unc) {
+            const unsigned slot = atomicAdd(sCnt, 1u);
+            if (slot < kListMax) sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
+        }
+        nUnc += (zone && !cert) ? 1u : 0u;
+    }
+    if (P.cert_stats) {
+        if (nUnc) atomicAdd(&sCnt[1], nUnc);
+    }
+    __syncthreads();
+
+    // ---- worklist: the exact path for what could not be certified ----
+    const unsigned n = sCnt[0];
+    unsigned bad = 0;
+#ifdef RAISR_EXP_OCC4
+    if (n) {                                               // (n is the same in every thread; every wave is past its last sV read)
+        if (threadIdx.x < 128) const_cast<uint2*>(sTab)[threadIdx.x] = P.tab14[threadIdx.x];
+        __syncthreads();
+    }
+#endif
+    if (n <= kListMax) {
+        // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
+        if (n) {
+            const int g = lane >> 4, l = lane & 15;
+            float wl[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) wl[i] = P.gauss_dev[min(l, 10) * 12 + i];
+            for (unsigned rd = (unsigned)w; 4u * rd < n; rd += 4u) {
+                const unsigned e = 4u * rd + (unsigned)g;
+                const unsigned ent = sList[min(e, n - 1u)];
+                const int prow = (ent >> 6) & 15, pcol = ent & 63;
+                float a, b, d;
+                exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
+                if (l == 0 && e < n) {
+                    unsigned hA, hB;
+                    flavour_hash(P, sTab, a, b, d, c0 + pcol, hA, hB);
+                    if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
+                    sH[prow * TW + pcol] = (uint8_t)hA;
+                    sH2[prow * TW + pcol] = (uint8_t)hB;
+                }
+            }
+        }
+    } else {
+        // long list (synthetic content, self-check mode): the whole tile through the all-exact routine (hash_phase; it
+        // rebuilds the gradient tile from the LR window), every wave busy.  The AVX2 flavour takes its out-of-line path.
+        unsigned hA[4], hB[4];
+        hash_phase<4, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int prow = 4 * w + j;
+            if (hA[j] != 0xFFu && ((certbits >> j) & 1u) &&
+                (sH[prow * TW + lane] != (uint8_t)hA[j] || (hB[j] != 0xFFu && sH2[prow * TW + lane] != (uint8_t)hB[j]))) bad++;
+            sH[prow * TW + lane] = (uint8_t)hA[j];
+            sH2[prow * TW + lane] = (uint8_t)hB[j];
+        }
+    }
+    if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
+    if (n) __syncthreads();                                // (n is the same in every thread)
+}
+
+// Test hook: the certified hash stage's decision for arbitrary APPROXIMATE tensor triples (a', b', d'): bucket and whether
+// it would be certified, by the very approx_hash the kernels run (flavour 0: AVX-512 table error, 1: AVX2).
+__global__ __launch_bounds__(256) void k_debug_approx_hash(const float* __restrict__ abd, unsigned n, PassParams P, SepW S, int fl,
+                                                           uint8_t* __restrict__ bucket_out, uint8_t* __restrict__ cert_out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    const float a = abd[3 * (size_t)i], b = abd[3 * (size_t)i + 1], d = abd[3 * (size_t)i + 2];
+    unsigned bucket;
+    bool cert = approx_hash(a, b, d, Q, S, fl, bucket);
+    if ((a + d) == 0.0f) { cert = true; bucket = (unsigned)P.zero_bucket[fl]; }
+    bucket_out[i] = (uint8_t)bucket;
+    cert_out[i] = cert ? 1 : 0;
+}

@@ -1,0 +1,99 @@
+// kernels_resize.h -- cheap upscale (stand-in for ippiResizeLinear, Raisr.cpp:947-958): k_resize, k_resize2x, k_copy
+// Included by device_abi.hip inside its anonymous namespace, in the order given there (gfx950 only; built with
+// -ffp-contract=off and without fast-math: every floating-point operation is ONE IEEE operation of the cited reference line).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// k_resize: centre-aligned bilinear with replicate border in exact integer arithmetic.
+// dst(y,x): n = (2d+1)*S - D, den = 2D per axis (reduced by gcd on the host: Sx,Dx,Sy,Dy).
+// ------------------------------------------------------------------------------------------------
+struct ResizeParams {
+    int sw, sh, dw, dh;
+    int spitch, dpitch;          // in elements
+    int Sx, Dx, Sy, Dy;          // reduced ratios
+    int tie_even;
+};
+
+__device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0, int& i1, int& f)
+{
+    const int n = (2 * d + 1) * S - D, den = 2 * D;
+    int q = n >= 0 ? n / den : -((-n + den - 1) / den);
+    f = n - q * den;
+    i0 = min(max(q, 0), size - 1);
+    i1 = min(max(q + 1, 0), size - 1);
+}
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= R.dw || y >= R.dh) return;
+    int x0, x1, fx, y0, y1, fy;
+    axis_tap(x, R.Sx, R.Dx, R.sw, x0, x1, fx);
+    axis_tap(y, R.Sy, R.Dy, R.sh, y0, y1, fy);
+    const long long denx = 2 * R.Dx, deny = 2 * R.Dy;
+    const TIn* r0 = src + (size_t)y0 * R.spitch;
+    const TIn* r1 = src + (size_t)y1 * R.spitch;
+    const long long top = (denx - fx) * (long long)r0[x0] + (long long)fx * r0[x1];
+    const long long bot = (denx - fx) * (long long)r1[x0] + (long long)fx * r1[x1];
+    const long long num = (deny - fy) * top + fy * bot;
+    const long long den = denx * deny;
+    long long q = (2 * num + den) / (2 * den);
+    if (R.tie_even && ((2 * num + den) % (2 * den) == 0) && (q & 1)) q--;
+    dst[(size_t)y * R.dpitch + x] = (TOut)q;
+}
+
+// 2x special case of the same arithmetic: weights {1,3}/4 per axis, out = (sum + 8) >> 4
+// (ties: +8 then >>4 is round-half-up; the half-even switch subtracts one when the discarded
+// bits are exactly 8 and the quotient is odd).  One thread produces 4 adjacent output pixels.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    int bx, by;
+    xcd_tile(bx, by);                                         // vertically adjacent blocks share input rows: keep them on one XCD
+    const int t = bx * 64 + (threadIdx.x & 63);               // group of 4 output columns
+    const int y = by * 4 + (threadIdx.x >> 6);
+    const int x0 = 4 * t;
+    if (x0 >= R.dw || y >= R.dh) return;
+    const int sy = y >> 1;
+    const int ya = (y & 1) ? sy : max(sy - 1, 0);             // far/near rows: even y -> (sy-1: 1, sy: 3)
+    const int yb = (y & 1) ? min(sy + 1, R.sh - 1) : sy;      //                odd  y -> (sy: 3, sy+1: 1)
+    const int wa = (y & 1) ? 3 : 1, wb = 4 - wa;
+    const TIn* ra = src + (size_t)ya * R.spitch;
+    const TIn* rb = src + (size_t)yb * R.spitch;
+    const int c = 2 * t;                                      // source columns c-1 .. c+2
+    const int cm = max(c - 1, 0), c1 = min(c + 1, R.sw - 1), c2 = min(c + 2, R.sw - 1), cc = min(c, R.sw - 1);
+    const int a0 = ra[cm], a1 = ra[cc], a2 = ra[c1], a3 = ra[c2];
+    const int b0 = rb[cm], b1 = rb[cc], b2 = rb[c1], b3 = rb[c2];
+    const int v0 = wa * a0 + wb * b0, v1 = wa * a1 + wb * b1, v2 = wa * a2 + wb * b2, v3 = wa * a3 + wb * b3;
+    int o[4] = {v0 + 3 * v1, 3 * v1 + v2, v1 + 3 * v2, 3 * v2 + v3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = (o[i] + 8) >> 4;
+        if (R.tie_even && ((o[i] & 15) == 8) && (q & 1)) q--;
+        o[i] = q;
+    }
+    TOut* d = dst + (size_t)y * R.dpitch + x0;
+    if (x0 + 3 < R.dw) {
+        if (sizeof(TOut) == 2 && ((reinterpret_cast<uintptr_t>(d) & 7) == 0)) {
+            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+        } else if (sizeof(TOut) == 1 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
+            *reinterpret_cast<unsigned*>(d) = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16) | ((unsigned)o[3] << 24);
+        } else {
+            d[0] = (TOut)o[0]; d[1] = (TOut)o[1]; d[2] = (TOut)o[2]; d[3] = (TOut)o[3];
+        }
+    } else {
+        for (int i = 0; i < 4 && x0 + i < R.dw; i++) d[i] = (TOut)o[i];
+    }
+}
+
+// same-size case of the cheap upscale (two-pass mode 2 runs pass 1 at input size, Raisr.cpp:960-975): widen/copy
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < R.dw && y < R.dh) dst[(size_t)y * R.dpitch + x] = (TOut)src[(size_t)y * R.spitch + x];
+}
+

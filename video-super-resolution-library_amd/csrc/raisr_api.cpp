@@ -499,6 +499,11 @@ RNLERRORTYPE RNLDeinit()
     dropContext();
     G.inited = false;
     for (auto &m : G.model) { m.bank.clear(); m.bank.shrink_to_fit(); }
+    // what RNLSetOpenCLContext stored belongs to the session that ends here: the caller may destroy its stream now, and the
+    // next RNLInit without a SetOpenCLContext call goes back to RAISR_HIP_DEVICE / device 0
+    G.externalStream = nullptr;
+    G.deviceChosen = false;
+    G.device = 0;
     return RNLErrorNone;
 }
 

@@ -89,6 +89,8 @@ int raisr_hip_stream_set_model(raisr_hip_stream* s, int pass_index, const float*
                                const double qstr[2], const double qcoh[2], int quant_angle)
 {
     if (!s) return RAISR_HIP_EINVAL;
+    for (size_t i = 0; i < s->lanes.size(); i++)
+        if (s->busy[i]) return RAISR_HIP_ESTATE;                   // a lane's kernels may still be reading its bank
     for (raisr_hip_ctx* c : s->lanes) {
         const int rc = raisr_hip_set_model(c, pass_index, bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
         if (rc != RAISR_HIP_OK) return rc;
@@ -100,6 +102,8 @@ int raisr_hip_stream_set_model(raisr_hip_stream* s, int pass_index, const float*
 int raisr_hip_stream_set_model_blob_device(raisr_hip_stream* s, int pass_index, const void* device_blob, size_t bytes, void* stream)
 {
     if (!s) return RAISR_HIP_EINVAL;
+    for (size_t i = 0; i < s->lanes.size(); i++)
+        if (s->busy[i]) return RAISR_HIP_ESTATE;
     for (raisr_hip_ctx* c : s->lanes) {
         const int rc = raisr_hip_set_model_blob_device(c, pass_index, device_blob, bytes, stream);
         if (rc != RAISR_HIP_OK) return rc;
@@ -124,6 +128,7 @@ int raisr_hip_stream_configure(raisr_hip_stream* s, const raisr_hip_config* cfg)
     if (!s || !cfg) return RAISR_HIP_EINVAL;
     for (size_t i = 0; i < s->lanes.size(); i++)
         if (s->busy[i]) return RAISR_HIP_ESTATE;                   // collect everything before changing the geometry
+    s->configured = false;                                         // lanes in mixed geometry are never submitted to: all of them or none
     for (raisr_hip_ctx* c : s->lanes) {
         const int rc = raisr_hip_configure(c, cfg);
         if (rc != RAISR_HIP_OK) return rc;
