@@ -43,6 +43,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
 VALU_FP32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md "Peak FP32 (vector)": 4 SIMD-32 per CU, all-FMA.
+VALU_FP16_PEAK_TFLOPS = 314.6                                # packed binary16 (v_pk_fma_f16): two lanes per fp32 lane, same issue rate
 # (scripts/valu_rate_probe.hip sustains 911 G wave-inst/s = 116.6 TFLOP/s of v_fma_f32 on this power-limited part.)
 # SURVEY.md s8d per-filtered-pixel ALGORITHMIC FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add,
 # hash ~60, filter 121 fma + 15 add.  This is the work the reference's algorithm defines per pixel; a kernel that
@@ -74,7 +75,8 @@ def parse():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration; the bench line is C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the c3_2pass / end_to_end / stream / parity legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c3_2pass / end_to_end / stream / parity / configs legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration legs (C1, C3, C4, C5)")
     ap.add_argument("--cpu-sample-frames", type=int, default=100, help="bounded CPU-baseline sample (~10-15 s on 16 cores)")
     ap.add_argument("--extra-frames", type=int, default=256, help="frames of each extra leg (c3_2pass, end_to_end, stream)")
     ap.add_argument("--frame-kind", default="natural", choices=["natural", "constant", "random", "checker"])
@@ -185,10 +187,10 @@ def source_hash():
     return h.hexdigest()
 
 
-def measured_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest profiles/traffic_r*.json whose recorded source hash is
-    the hash of the kernel sources in this tree (the PMC passes are separate rocprofv3 runs, scripts/profile_gpu.sh);
-    None otherwise -- a stale figure is not quoted."""
+def measured_traffic(kernel, config="C2"):
+    """HBM-side bytes per launch of `kernel` in configuration `config` from the newest profiles/traffic_r*.json recorded for
+    that configuration whose source hash is the hash of the kernel sources in this tree (the PMC passes are separate
+    rocprofv3 runs, scripts/profile_gpu.sh); None otherwise -- a stale figure is not quoted."""
     pdir = os.path.join(ROOT, "profiles")
     try:
         cands = sorted(f for f in os.listdir(pdir) if f.startswith("traffic_r") and f.endswith(".json"))
@@ -200,7 +202,7 @@ def measured_traffic(kernel):
             j = json.load(open(os.path.join(pdir, fn)))
         except (OSError, ValueError):
             continue
-        if j.get("source_sha256") != cur:
+        if j.get("source_sha256") != cur or j.get("config", "C2") != config or j.get("variant_env"):
             continue
         if kernel in j.get("per_kernel_bytes", {}):
             return int(j["per_kernel_bytes"][kernel]), fn
@@ -300,6 +302,51 @@ def isolated_kernel_ms(lanes, d_in, d_out, wl, torch, iters=24):
 def filtered_zone_px(w, h):
     c_final = 6 + 8 * ((w - 12) // 8)
     return max(0, c_final - 6) * max(0, h - 12)
+
+
+def roofline_of(wl, kern, iso, lanes_n):
+    """`roofline` object of one workload from the HIP-event timings of its kernels: `kern` = per-kernel totals over the timed
+    region (lanes_n frames in flight), `iso` = per-launch milliseconds of the same kernels with nothing else on the chip."""
+    roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    dom = next((k for k in DOMINANT if k in kern and kern[k]["count"]), None)
+    if not dom:
+        return roofline
+    per_launch = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3           # seconds
+    launches_per_frame = wl.passes                                           # one launch of the dominant kernel = one pass of one frame
+    achieved = wl.algo_bytes / launches_per_frame / per_launch / 1e9
+    traffic, traffic_src = measured_traffic(dom, wl.name)
+    # NOTE: `avg_launch_ms` is measured while `lanes` frames are in flight, so launches of different lanes share the
+    # chip and each one is stretched accordingly; `isolated_launch_ms` is the same launch alone on the chip (the duration
+    # roofline.valu divides by).  Throughput follows the overlapped figure: fps ~ lanes / (sum of the overlapped kernel times).
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(per_launch * 1e3, 4),
+                "isolated_launch_ms": round(iso[dom], 4) if dom in iso else None,
+                "algorithmic_bytes_per_launch": wl.algo_bytes // launches_per_frame,
+                "lanes_overlapped": lanes_n,
+                "note": "path is fp32-VALU / LDS / vector-L1 bound (~1.3 kFLOP per output pixel vs 1.25 compulsory bytes); the HBM "
+                        "fraction is reported as required, roofline.valu is the binding figure (DESIGN.md s5)"}
+    if dom in iso:
+        roofline["frac_isolated"] = round(wl.algo_bytes / launches_per_frame / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+    # the binding roofline: algorithmic FLOPs of the hash+filter stages over their isolated durations
+    stage_kernels = [k for k in iso if k.startswith(("k_hash", "k_filter", "k_fix"))]
+    if stage_kernels:
+        zone = filtered_zone_px(wl.out_w, wl.out_h)
+        if wl.mode == 2 and wl.passes == 2:          # pass 1 of mode 2 runs at input size; average the two launches
+            zone = (filtered_zone_px(wl.in_w, wl.in_h) + zone) / 2
+        flop = zone * (HASH_FLOP_PER_PIXEL + FILTER_FLOP_PER_PIXEL)
+        t_iso = sum(iso[k] for k in stage_kernels) * 1e-3
+        tflops = flop / t_iso / 1e12
+        fp16 = wl.asm == 5
+        peak = VALU_FP16_PEAK_TFLOPS if fp16 else VALU_FP32_PEAK_TFLOPS
+        roofline["valu"] = {"kernels": stage_kernels, "isolated_ms": round(t_iso * 1e3, 4),
+                            "flop_per_frame_pass": int(flop), "achieved": round(tflops, 2), "peak": peak,
+                            "unit": ("TFLOP/s (packed binary16 VALU" if fp16 else "TFLOP/s (fp32 VALU") + ", algorithmic FLOPs of SURVEY s8d)",
+                            "frac": round(tflops / peak, 4)}
+        if not fp16:                                 # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
+            roofline["valu"].update({"sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)})
+        roofline["binding"] = "f16-valu" if fp16 else "fp32-valu"
+    return roofline
 
 
 class _stdout_to_stderr:
@@ -442,6 +489,54 @@ def parity_leg(R, wl, gpu, blobs, kind, fast=None):
             "frame": f"{wl.name} {kind} frame 0, Y plane"}
 
 
+def certify_leg(R, wl, gpu, blobs, frames):
+    """Self-check of the certified hash stage on the frames that were benchmarked: every pixel ALSO takes the reference's exact
+    instruction sequence and a certified bucket that differs from it is counted (`certified_wrong`, must be 0);
+    `uncertified_frac` = share of the filtered pixels the production kernel sends to the exact path."""
+    if wl.asm == 5:
+        return {"applies": False, "why": "binary16 numerics: every pixel takes the exact path (DESIGN.md s5: no sound bound for binary16 accumulation)"}
+    res = {}
+    for check in (False, True):
+        d = R.RaisrDevice(gpu)
+        try:
+            for p in range(wl.passes):
+                d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
+            d.configure(wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode, hash_variant=wl.asm)
+            d.certify_debug(True, check)
+            out = np.zeros((wl.out_h, wl.out_w), frames[0].dtype)
+            for f in frames:
+                d.process_host(f, out)
+            st = d.certify_stats()
+        finally:
+            d.close()
+        if check:
+            res["certified_wrong"] = st["mismatches"]
+            res["buckets_compared"] = st["pixels"]
+        else:
+            res["uncertified_frac"] = round(st["uncertain"] / max(1, st["pixels"]), 6)
+    res["frames"] = len(frames)
+    return res
+
+
+def config_leg(R, torch, name, gpu, load_blobs, lanes_n, n_frames, fence, kind):
+    """One BASELINE.json configuration as first-class evidence: the headline loop (frames resident in HBM, `lanes_n` in flight),
+    per-kernel HIP-event timings, isolated launch durations, both rooflines, and the certified hash stage's self-check on the
+    frames that ran."""
+    w = Workload(name)
+    b = load_blobs(w)
+    frames = w.frames(kind, range(8 if w.out_w <= 3840 else 4))
+    dt, kern, lanes, d_in, d_out = device_loop(R, torch, w, gpu, b, lanes_n, frames, n_frames, 1, 1, fence, True)
+    iso = isolated_kernel_ms(lanes, d_in, d_out, w, torch, iters=12)
+    for d in lanes:
+        d.close()
+    del d_in, d_out
+    fps = n_frames / dt
+    return {"workload": w.desc, "fps": round(fps, 2), "value": round(w.out_w * w.out_h * fps / 1e6, 2), "unit": "MP/s", "frames": n_frames,
+            "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()},
+            "roofline": roofline_of(w, kern, iso, lanes_n),
+            "certify": certify_leg(R, w, gpu, b, frames[:4])}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -517,6 +612,7 @@ def main():
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
         frames_total = len(mine) * world
         lanes = []
+        host_frames = wl.frames(args.frame_kind, range(4))
     else:
         uniq = min(nf, 8)
         # each rank owns its own frames of the (virtual) stream: frame index = rank + world * i
@@ -546,39 +642,8 @@ def main():
 
     if rank == 0:
         mp_s = wl.out_w * wl.out_h * frames_total / dt / 1e6
-        # roofline of the dominant kernel: algorithmic bytes per launch / mean launch time
-        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
-        dom = next((k for k in DOMINANT if k in kern and kern[k]["count"]), None)
-        if dom:
-            per_launch = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3           # seconds
-            achieved = wl.algo_bytes / wl.passes / per_launch / 1e9                  # one launch handles one pass of one frame
-            traffic, traffic_src = measured_traffic(dom)
-            # NOTE: `avg_launch_ms` is measured while `lanes` frames are in flight, so launches of different lanes share the
-            # chip and each one is stretched accordingly; the isolated figure is in kernels_isolated_ms / roofline.valu.
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_ms": round(per_launch * 1e3, 4),
-                        "algorithmic_bytes_per_launch": wl.algo_bytes // wl.passes,
-                        "lanes_overlapped": args.lanes,
-                        "note": "path is fp32-VALU / LDS-bandwidth bound (~1.3 kFLOP per output pixel vs 1.25 compulsory bytes); the HBM "
-                                "fraction is reported as required, roofline.valu is the binding figure (DESIGN.md s5)"}
-            # the binding roofline: algorithmic fp32 FLOPs of the hash+filter stages over their isolated durations
-            stage_kernels = [k for k in iso if k.startswith(("k_hash", "k_filter"))]
-            if stage_kernels:
-                zone = filtered_zone_px(wl.out_w, wl.out_h)
-                if wl.mode == 2 and wl.passes == 2:          # pass 1 of mode 2 runs at input size; average the two launches
-                    zone = (filtered_zone_px(wl.in_w, wl.in_h) + zone) / 2
-                flop = zone * (HASH_FLOP_PER_PIXEL + FILTER_FLOP_PER_PIXEL)
-                t_iso = sum(iso[k] for k in stage_kernels) * 1e-3
-                tflops = flop / t_iso / 1e12
-                roofline["valu"] = {"kernels": stage_kernels, "isolated_ms": round(t_iso * 1e3, 4),
-                                    "flop_per_frame_pass": int(flop), "achieved": round(tflops, 2),
-                                    "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s (fp32 VALU, algorithmic FLOPs of SURVEY s8d)",
-                                    "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4),
-                                    # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
-                                    "sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)}
-                roofline["binding"] = "fp32-valu"
+        roofline = roofline_of(wl, kern, iso, args.lanes)
         fast_level = lanes[0].fast() if lanes and hasattr(lanes[0], "fast") else int(os.environ.get("RAISR_HIP_FAST", "0") or 0)
         for d in lanes:
             d.close()
@@ -604,7 +669,22 @@ def main():
             leg("end_to_end", lambda: end_to_end_leg(R, wl, args.extra_frames, gpu))
             if hasattr(R, "RaisrStream"):
                 leg("stream", lambda: stream_leg(R, wl, gpu, args.extra_frames, blobs=blobs))
-            leg("parity", lambda: parity_leg(R, wl, gpu, blobs, args.frame_kind))
+            def parity_all():
+                par = parity_leg(R, wl, gpu, blobs, args.frame_kind)
+                par["certify"] = certify_leg(R, wl, gpu, blobs, host_frames)        # self-check over every frame that was benchmarked
+                return par
+            leg("parity", parity_all)
+            if wl.name == "C2" and not args.passes and not args.no_configs:
+                # every BASELINE.json configuration with its own rooflines (C2 = this line's headline; C5 with fewer frames: 8K planes)
+                cfgs = {"C2": {"workload": wl.desc, "fps": round(frames_total / dt, 2), "value": round(mp_s, 2), "unit": "MP/s",
+                               "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()}, "roofline": "see the top-level roofline object",
+                               "certify": extras.get("parity", {}).get("certify")}}
+                for cname in ("C1", "C3", "C4", "C5"):
+                    try:
+                        cfgs[cname] = config_leg(R, torch, cname, gpu, load_blobs, args.lanes, args.extra_frames if cname != "C5" else max(32, args.extra_frames // 4), fence, args.frame_kind)
+                    except Exception as e:
+                        cfgs[cname] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+                extras["configs"] = cfgs
             if wl.pixel_types == 4 and wl.bits <= 10 and wl.asm != 5 and hasattr(R.RaisrDevice, "set_fast"):
                 def fast_leg():
                     # NOT a parity path and never the headline: the opt-in matrix-core filter stage, same loop as `value`

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""usage: scripts/pmc_summarize.py <dir with g*/…/*_counter_collection.csv>  -- per-kernel averages of every counter"""
+"""usage: scripts/pmc_summarize.py <dir> [<dir> ...]  -- per-kernel averages of every counter found in *_counter_collection.csv below the directories"""
 import collections, csv, glob, os, re, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(sys.argv[1], "g*", "*", "*_counter_collection.csv")):
+files = []
+for d in sys.argv[1:]:
+    files += glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+for f in files:
     for r in csv.DictReader(open(f)):
         m = re.search(r"k_\w+", r["Kernel_Name"])
         if m:

@@ -22,8 +22,13 @@ def short(name):
 
 
 variant = open(os.path.join(src, "variant.txt")).read().strip() if os.path.exists(os.path.join(src, "variant.txt")) else ""
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1` (C2: 1080p->4K 2x, highres, 1-pass, 4 lanes x 768 frames/step)"
-         + (f", environment: `{variant}`" if variant else ""), ""]
+m = re.search(r"--config\s+(C\d)", variant)
+config = m.group(1) if m else "C2"
+variant_env = " ".join(t for t in variant.split() if "=" in t and not t.startswith("--"))
+DESC = {"C1": "540p->1080p 2x, lowres, 1-pass, AVX2 numerics", "C2": "1080p->4K 2x, highres, 1-pass", "C3": "1080p->4K 2x, highres, 2-pass",
+        "C4": "720p->1080p 1.5x, denoise, 2-pass mode 2, binary16 numerics", "C5": "4K->8K 2x, highres, 10-bit"}
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-extras --config {config} --steps 3 --warmup 1` ({config}: {DESC[config]}, 4 lanes x 768 frames/step)"
+         + (f", environment: `{variant_env}`" if variant_env else ""), ""]
 f = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # newest run first
 if f:
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
@@ -90,7 +95,7 @@ if pmc:
             traffic[k] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if traffic:
         lines += ["## HBM-side bytes per launch (2 * FETCH_SIZE + WRITE_SIZE) * 1024", "", "```", json.dumps(traffic, indent=1), "```", ""]
-        dom = next((k for k in ("k_hashfilter_ac", "k_hashfilter", "k_filter_lds16", "k_hash") if k in traffic), None)
+        dom = next((k for k in ("k_hashfilter_ac", "k_hashfilter", "k_hashfilter16", "k_filter_lds16", "k_hash") if k in traffic), None)
         import hashlib
         hs = hashlib.sha256()
         cs = os.path.join(root, "video-super-resolution-library_amd", "csrc")
@@ -98,7 +103,7 @@ if pmc:
             if fn.endswith((".hip", ".h", ".cpp")):
                 hs.update(fn.encode()); hs.update(open(os.path.join(cs, fn), "rb").read())
         json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic,
-                   "source_sha256": hs.hexdigest(), "variant": variant,
+                   "source_sha256": hs.hexdigest(), "config": config, "variant_env": variant_env,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--lanes 1); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                              "gfx950 FETCH_SIZE half-count confirmed on k_blend's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
                   open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)

@@ -387,6 +387,12 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             else
 #endif
+#ifdef RAISR_EXP_PERSIST
+                if (getenv("RAISR_HIP_PERSIST")) {
+                    const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST")));
+                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y);
+                } else
+#endif
                 hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else if (c->fused) {

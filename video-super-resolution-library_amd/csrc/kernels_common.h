@@ -53,6 +53,15 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by)
     bx = (int)(t - (unsigned)by * gx);
 }
 
+// xcd_tile for a linear tile index t of a persistent grid whose size is a multiple of 8 (so t % 8 == blockIdx.x % 8)
+__device__ __forceinline__ void xcd_tile_of(unsigned t, unsigned gx, unsigned n, int& bx, int& by)
+{
+    const unsigned n8 = n & ~7u;
+    const unsigned u = t < n8 ? (t & 7u) * (n8 >> 3) + (t >> 3) : t;
+    by = (int)(u / gx);
+    bx = (int)(u - (unsigned)by * gx);
+}
+
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on
 // gfx950 the fence makes every wave wait for ALL its outstanding global loads and stores (s_waitcnt vmcnt(0)) -- which
 // turns a register prefetch of the next tile into a stall, and makes a persistent workgroup wait for the write
@@ -82,12 +91,12 @@ struct TileRegs {
 // global -> registers half of stage_tile (all loads in flight, nothing waits): lets a persistent workgroup fetch the
 // next tile while it computes the current one
 template <int LH, int LWLOAD, typename T>
-__device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TileRegs<LH, LWLOAD, T>& R)
+__device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TileRegs<LH, LWLOAD, T>& R, unsigned tid = threadIdx.x)
 {
     static_assert(LWLOAD > 64 && LWLOAD <= 128, "a tile row is one 64-lane sweep plus a remainder");
     using TR = TileRegs<LH, LWLOAD, T>;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the row arithmetic stays scalar
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: the row arithmetic stays scalar
     __builtin_assume(w >= 0 && w < 4);
     // main part: wave w sweeps columns [0,64) of rows w, w+4, ...: one clamped column index per lane for all rows
     const int gxm = min(max(x0 + lane, 0), W - 1);
@@ -99,7 +108,7 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, 
     // remainder: the REM right-hand columns of all rows, spread linearly over the block
 #pragma unroll
     for (unsigned it = 0; it < TR::NRL; it++) {
-        const unsigned idx = min(threadIdx.x + 256u * it, TR::NR - 1u);
+        const unsigned idx = min(tid + 256u * it, TR::NR - 1u);
         const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
         const int gy = min(max(y0 + ty, 0), H - 1), gx = min(max(x0 + tx, 0), W - 1);
         R.vr[it] = src[(unsigned)gy * (unsigned)pitch + (unsigned)gx];
@@ -108,11 +117,11 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ src, int pitch, 
 
 // registers -> LDS half (converting each sample to TL)
 template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
-__device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL* sL)
+__device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL* sL, unsigned tid = threadIdx.x)
 {
     using TR = TileRegs<LH, LWLOAD, T>;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(w >= 0 && w < 4);
 #pragma unroll
     for (int it = 0; it < TR::NM; it++) {
@@ -121,17 +130,17 @@ __device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL*
     }
 #pragma unroll
     for (unsigned it = 0; it < TR::NRL; it++) {
-        const unsigned idx = threadIdx.x + 256u * it;
+        const unsigned idx = tid + 256u * it;
         const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
         if (idx < TR::NR) sL[ty * LSTRIDE + tx] = (TL)(float)R.vr[it];
     }
 }
 
 template <int LH, int LWLOAD, int LSTRIDE, typename TL, typename T>
-__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL)
+__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int pitch, int W, int H, int y0, int x0, TL* sL, unsigned tid = threadIdx.x)
 {
     TileRegs<LH, LWLOAD, T> R;
-    load_tile<LH, LWLOAD>(src, pitch, W, H, y0, x0, R);
-    store_tile<LH, LWLOAD, LSTRIDE>(R, sL);
+    load_tile<LH, LWLOAD>(src, pitch, W, H, y0, x0, R, tid);
+    store_tile<LH, LWLOAD, LSTRIDE>(R, sL, tid);
 }
 

@@ -35,19 +35,17 @@ __device__ __forceinline__ float tree16(float acc)
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
 template <int LW>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
-                                             int c0, int r0, float* __restrict__ hr)
+                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x)
 {
     constexpr int TW = 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l = lane & 15;
     int off[8];
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
         const int k = 16 * ch + l;
         off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
-#ifdef RAISR_EXP_OCC4
         asm volatile("" : "+v"(off[ch]));                      // one register per tap: left alone, the compiler keeps row and column part apart (16 VGPRs)
-#endif
     }
 
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
@@ -201,41 +199,21 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
 // pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
 // PART (profiling aid, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only (bucket 0).
-#ifdef RAISR_EXP_OCC4
-#define RAISR_AC_WGS 4
-#else
-#define RAISR_AC_WGS 3
-#endif
-template <typename T, int PART = 0>
-__global__ __launch_bounds__(256, RAISR_AC_WGS) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
-                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+// Four workgroups per CU (16 waves): 128 VGPRs and 40 384 B of LDS (4 x 40 960 = the CU's 160 KB).  Round 2 ran three (144 VGPRs,
+// 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
+// filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
+// one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT>
+__device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
+                                                   uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
+                                                   float* sL, GT* sG, float4* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x)
 {
     constexpr int TW = 64, TH = 16;
-    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
-    __shared__ float sL[LH * LW];
-    using GT = typename GradOf<T>::type;
-    __shared__ GT sG[GH * GW_];
-    __shared__ float4 sV[3 * 4 * GW_];
-#ifdef RAISR_EXP_OCC4
-    uint2* sTab = reinterpret_cast<uint2*>(sV);   // the exact path's table takes sV's place once the H pass is done (hash_phase_ac)
-#else
-    __shared__ uint2 sTab[128];
-#endif
-    __shared__ uint8_t sH[TH * TW];
-    __shared__ uint8_t sH2[TH * TW];
-    __shared__ uint16_t sList[kListMax];      // worklist entries
-    __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int bx, by;
-    xcd_tile(bx, by);
+    const int lane = tid & 63, w = tid >> 6;
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
-#ifndef RAISR_EXP_OCC4
-    if (threadIdx.x < 128) sTab[threadIdx.x] = P.tab14[threadIdx.x];
-#endif
-    if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
-    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    if (tid < 3) sCnt[tid] = 0;
+    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL, tid);
     __syncthreads();
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
         auto grad = [&](int ty, int tx) {
@@ -251,16 +229,16 @@ __global__ __launch_bounds__(256, RAISR_AC_WGS) void k_hashfilter_ac(const T* __
         constexpr unsigned NR = GH * (GW_ - 64);
 #pragma unroll
         for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {
-            const unsigned idx = threadIdx.x + 256u * it;
+            const unsigned idx = tid + 256u * it;
             const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
             if (idx < NR) grad(ty, tx);
         }
     }
     __syncthreads();
-    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0);
+    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
     else {
         // P.cert_check doubles as the bucket pattern of this profiling aid: 0 = every row of the bank, 1 = one row, 2 = sixteen rows
-        for (int i = threadIdx.x; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
+        for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
         __syncthreads();
     }
     if (P.write_hash) {
@@ -271,14 +249,66 @@ __global__ __launch_bounds__(256, RAISR_AC_WGS) void k_hashfilter_ac(const T* __
             if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
         }
     }
-    if (P.cert_stats && threadIdx.x == 0) {
+    if (P.cert_stats && tid == 0) {
         const int zr = min(TH, P.H - kMargin - r0), zc = min(TW, P.c_final - c0);
         if (sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
-    if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr);
-    else if (sH[threadIdx.x] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+    if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
+    else if (sH[tid] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
 }
+
+template <typename T, int PART = 0>
+__global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+{
+    constexpr int TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
+    __shared__ float sL[LH * LW];
+    using GT = typename GradOf<T>::type;
+    __shared__ GT sG[GH * GW_];
+    __shared__ float4 sV[3 * 4 * GW_];
+    uint2* sTab = reinterpret_cast<uint2*>(sV);   // the exact path's table takes sV's place once the H pass is done (hash_phase_ac)
+    __shared__ uint8_t sH[TH * TW];
+    __shared__ uint8_t sH2[TH * TW];
+    __shared__ uint16_t sList[kListMax];      // worklist entries
+    __shared__ unsigned sCnt[3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
+
+    int bx, by;
+    xcd_tile(bx, by);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
+}
+
+#ifdef RAISR_EXP_PERSIST
+// Experiment: the same tile routine in a persistent grid (4 workgroups per CU walk the tiles in XCD-aware order).
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                           uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y)
+{
+    constexpr int TW = 64, TH = 16;
+    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
+    __shared__ float sL[LH * LW];
+    using GT = typename GradOf<T>::type;
+    __shared__ GT sG[GH * GW_];
+    __shared__ float4 sV[3 * 4 * GW_];
+    uint2* sTab = reinterpret_cast<uint2*>(sV);
+    __shared__ uint8_t sH[TH * TW];
+    __shared__ uint8_t sH2[TH * TW];
+    __shared__ uint16_t sList[kListMax];
+    __shared__ unsigned sCnt[3];
+    const unsigned ntiles = (unsigned)(tiles_x * tiles_y);
+#pragma unroll 1
+    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int bx, by;
+        xcd_tile_of(t, (unsigned)tiles_x, ntiles, bx, by);
+        unsigned tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                      // opaque per tile: keeps the tile routine's lane-dependent set-up inside the loop
+        __builtin_assume(tid < 256u);                      // (hoisted, it costs 52 spilled registers per lane)
+        hashfilter_ac_tile<T, 0, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, tid);
+        __syncthreads();                                   // every wave is done with this tile's LDS
+    }
+}
+#endif
 
 

@@ -171,11 +171,11 @@ template <typename T> struct GradOf { using type = f2; };
 template <int R, bool AVX2ALL, int LW, typename GT = f2>
 __device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, GT* sG,
                                            const uint2* sTab, const uint16_t* sLut, int c0, int r0,
-                                           unsigned (&hA)[R], unsigned (&hB)[R])
+                                           unsigned (&hA)[R], unsigned (&hB)[R], unsigned tid = threadIdx.x)
 {
     constexpr int TH = 4 * R;
     constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
     {
         auto grad = [&](int ty, int tx) {
@@ -191,7 +191,7 @@ __device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw
         constexpr unsigned NR = GH * (GW_ - 64);
 #pragma unroll
         for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {                           // the 10 right-hand columns
-            const unsigned idx = threadIdx.x + 256u * it;
+            const unsigned idx = tid + 256u * it;
             const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
             if (idx < NR) grad(ty, tx);
         }

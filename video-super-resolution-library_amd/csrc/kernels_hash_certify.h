@@ -158,10 +158,10 @@ __device__ __forceinline__ void exact_tensor16(const GT* sG, const float (&wl)[1
 // on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4),
 // results as float4 per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
 template <typename GT>
-__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4])
+__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4], unsigned tid = threadIdx.x)
 {
     constexpr int GW_ = 74;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     auto vpass = [&](int x, int rg) {
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -216,13 +216,13 @@ constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilte
 template <int LW, typename GT>
 __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, float4* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
-                                              int c0, int r0)
+                                              int c0, int r0, unsigned tid = threadIdx.x)
 {
     constexpr int GW_ = 74, TW = 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) sCnt[0] = 0;
+    const int lane = tid & 63, w = tid >> 6;
+    if (tid == 0) sCnt[0] = 0;
     float ta[4], tb[4], td[4];
-    tensor_ac(S, sG, sV, ta, tb, td);
+    tensor_ac(S, sG, sV, ta, tb, td, tid);
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
@@ -261,12 +261,10 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
     unsigned bad = 0;
-#ifdef RAISR_EXP_OCC4
-    if (n) {                                               // (n is the same in every thread; every wave is past its last sV read)
-        if (threadIdx.x < 128) const_cast<uint2*>(sTab)[threadIdx.x] = P.tab14[threadIdx.x];
+    if (n) {                                               // the table of VRCP14 / VRSQRT14 takes sV's place (n is the same in every thread;
+        if (tid < 128) const_cast<uint2*>(sTab)[tid] = P.tab14[tid];     // every wave is past its last sV read)
         __syncthreads();
     }
-#endif
     if (n <= kListMax) {
         // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
         if (n) {
@@ -293,7 +291,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         // long list (synthetic content, self-check mode): the whole tile through the all-exact routine (hash_phase; it
         // rebuilds the gradient tile from the LR window), every wave busy.  The AVX2 flavour takes its out-of-line path.
         unsigned hA[4], hB[4];
-        hash_phase<4, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB);
+        hash_phase<4, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB, tid);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int prow = 4 * w + j;

@@ -22,15 +22,6 @@ struct FixLists {
 constexpr unsigned kSparseMax = 96;          // a tile with more uncertain pixels than this is re-hashed as a whole
 constexpr unsigned kDenseTile = 0xFFFFFFFFu;
 
-// xcd_tile for a linear tile index t of a persistent grid whose size is a multiple of 8 (so t % 8 == blockIdx.x % 8)
-__device__ __forceinline__ void xcd_tile_of(unsigned t, unsigned gx, unsigned n, int& bx, int& by)
-{
-    const unsigned n8 = n & ~7u;
-    const unsigned u = t < n8 ? (t & 7u) * (n8 >> 3) + (t >> 3) : t;
-    by = (int)(u / gx);
-    bx = (int)(u - (unsigned)by * gx);
-}
-
 // Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the next tile's LR window
 // into registers while it computes the current one.
 template <typename T>
