@@ -53,4 +53,12 @@ RNLERRORTYPE RNLSetOpenCLContext(void *clContext, void *clDevice, int platformOr
 /* Release the device context and all HBM planes.  Replaces Library/Raisr.cpp:1842 RNLDeinit. */
 RNLERRORTYPE RNLDeinit();
 
+/* Asynchronous frames (extension, see RaisrHandler.h): up to `depth` frames in flight. */
+RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth);
+RNLERRORTYPE RNLSubmit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
+                       VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb,
+                       BlendingMode blend = CountOfBitsChanged);
+RNLERRORTYPE RNLCollect();
+int RNLFramesInFlight();
+
 #endif /* RAISR_H */

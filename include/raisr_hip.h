@@ -185,6 +185,7 @@ int  raisr_hip_stream_set_model_blob_device(raisr_hip_stream *s, int pass_index,
                                             void *stream);                              /* after raisr_hip_broadcast_model_blob */
 int  raisr_hip_stream_set_fast(raisr_hip_stream *s, int level);                        /* raisr_hip_set_fast on every lane; nothing in flight */
 int  raisr_hip_stream_configure(raisr_hip_stream *s, const raisr_hip_config *cfg);
+int  raisr_hip_stream_set_blending(raisr_hip_stream *s, int blending);                 /* BlendingMode of the frames submitted from now on */
 int  raisr_hip_stream_submit(raisr_hip_stream *s,
                              const void *in_y, size_t in_y_pitch, void *out_y, size_t out_y_pitch,
                              const void *in_u, size_t in_u_pitch, void *out_u, size_t out_u_pitch,
@@ -194,7 +195,7 @@ int  raisr_hip_stream_collect(raisr_hip_stream *s);
 int  raisr_hip_stream_in_flight(const raisr_hip_stream *s);
 void *raisr_hip_host_alloc(size_t bytes);            /* page-locked host memory for frame planes */
 void raisr_hip_host_free(void *p);
-int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns */
+int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns; RAISR_HIP_ESTATE: (part of) the range is page-locked already */
 int  raisr_hip_host_unregister(void *p);
 
 /* NON-bit-exact fast mode (north_star's MFMA question; off by default, RAISR_HIP_FAST=1 turns it on at

@@ -46,6 +46,13 @@ def test_pure_host_entry_points_work_without_a_gpu():
     assert hdr[:4].tobytes() == b"RASR" and hdr[4:16].view(np.int32).tolist() == [216, 4, 24]
     assert np.float32(hdr[16:20].view(np.float32)[0]) == np.float32(24) / np.float32(3.141592653)
     assert b"raisr-hip" in L.raisr_hip_version()
+    # asynchronous plugin entries: state checks come before anything touches a device
+    assert R.RNLHandler_FramesInFlight() == 0
+    assert R.RNLHandler_Collect() == R.RNLErrorBadParameter
+    assert R.RNLHandler_SetAsyncDepth(17) == R.RNLErrorBadParameter and R.RNLHandler_SetAsyncDepth(4) == 0
+    y = np.zeros((8, 8), np.uint8)
+    assert R.RNLHandler_Submit((y, y, y), (y, y, y)) == R.RNLErrorBadParameter          # not initialised
+    assert R.RNLHandler_Deinit() == 0
 
 
 def test_headers_are_plain_c_and_link_from_a_c_program(tmp_path):

@@ -303,3 +303,117 @@ def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream):
     assert np.array_equal(got_y, ref)
     assert np.array_equal(ou[:, :w].cpu().numpy().view(ndt), O.resize(u, w, h).astype(ndt))
     assert np.array_equal(ov[:, :w].cpu().numpy().view(ndt), O.resize(v, w, h).astype(ndt))
+
+
+@pytest.mark.parametrize("bits,asm,passes,mode,depth", [(8, 2, 1, 1, 4), (10, 2, 2, 1, 2), (8, 5, 2, 2, 3), (8, 6, 1, 1, 1)])
+def test_async_submit_collect_frames_equal_the_oracle_in_order(bits, asm, passes, mode, depth):
+    """RNLHandler_Submit / _Collect (the call sequence of the FFmpeg filter with async=N: submit frame n, collect frame n - N,
+    drain at EOF): every collected frame is the oracle's frame, in submission order; a full ring refuses the next Submit."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h = 176, 100
+    fold = "filters_2x/filters_denoise" if mode == 2 else "filters_2x/filters_highres"
+    dt = np.uint8 if bits == 8 else np.uint16
+    n = 11
+    ys = [synth.natural_y(w, h, bits, seed=100 + s) for s in range(n)]
+    us = [synth.random_y(w // 2, h // 2, bits, seed=200 + s).astype(dt) for s in range(n)]
+    vs = [synth.random_y(w // 2, h // 2, bits, seed=300 + s).astype(dt) for s in range(n)]
+    ref_asm = 2 if asm == 6 else asm
+    refs = [oracle_y(y, ("x", fold, (2, 1), bits, passes, mode, ref_asm, False)) for y in ys]
+    outs = [(_strided(np.zeros((2 * h, 2 * w), dt), 40), np.zeros((h, w), dt), np.zeros((h, w), dt)) for _ in range(n)]
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, bits, R.VideoRange, 20, asm, passes, mode) == 0
+    try:
+        assert R.RNLHandler_Submit((ys[0], us[0], vs[0]), outs[0]) == R.RNLErrorBadParameter          # before SetRes
+        assert R.RNLHandler_SetRes((ys[0], us[0], vs[0]), outs[0]) == 0
+        assert R.RNLHandler_Submit((ys[0], us[0], vs[0]), outs[0]) == R.RNLErrorBadParameter          # no ring asked for
+        assert R.RNLHandler_Collect() == R.RNLErrorBadParameter
+        assert R.RNLHandler_SetAsyncDepth(17) == R.RNLErrorBadParameter
+        assert R.RNLHandler_SetAsyncDepth(depth) == 0
+        built = min(depth, 4)
+        collected = 0
+
+        def collect():
+            nonlocal collected
+            assert R.RNLHandler_Collect() == 0
+            oy, ou, ov = outs[collected]
+            assert np.array_equal(oy, refs[collected]), (collected, int((oy != refs[collected]).sum()))
+            assert np.array_equal(ou, O.resize(us[collected], w, h).astype(dt)) and np.array_equal(ov, O.resize(vs[collected], w, h).astype(dt))
+            collected += 1
+        for i in range(n):
+            if R.RNLHandler_FramesInFlight() == built:
+                assert R.RNLHandler_Submit((ys[i], us[i], vs[i]), outs[i]) == R.RNLErrorInsufficientResources
+                collect()
+            assert R.RNLHandler_Submit((ys[i], us[i], vs[i]), outs[i]) == 0
+        assert R.RNLHandler_SetAsyncDepth(0) == R.RNLErrorBadParameter                                # frames in flight
+        while R.RNLHandler_FramesInFlight():
+            collect()
+        assert collected == n and R.RNLHandler_Collect() == R.RNLErrorBadParameter
+        # the synchronous entry still works next to the ring, and a wrong geometry is refused
+        assert R.RNLHandler_Process((ys[1], us[1], vs[1]), outs[0]) == 0 and np.array_equal(outs[0][0], refs[1])
+        assert R.RNLHandler_Submit((ys[0][:-2], us[0], vs[0]), outs[0]) == R.RNLErrorBadParameter
+        assert R.RNLHandler_SetAsyncDepth(0) == 0
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+
+
+def test_registered_planes_survive_free_and_reuse():
+    """RNLProcess page-locks the caller's planes on first sight and remembers them (csrc/raisr_api.cpp: PinCache).  A host may
+    free a buffer and get the same addresses back from its allocator with different pages behind them: the remembered
+    registration must not make a later frame read or write stale pages.  Frames from freshly allocated, freed and
+    re-allocated planes (malloc returns the same addresses for same-sized blocks) against the oracle, many times; then more
+    distinct buffers than the cache holds."""
+    import ctypes
+    import raisr_hip as R
+    import synth
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    w, h = 480, 272                                      # planes above the cache's 64 KB threshold and above malloc's mmap threshold
+    fold = "filters_2x/filters_highres"
+    case = ("x", fold, (2, 1), 8, 1, 1, 2, False)
+    ys = [synth.natural_y(w, h, 8, seed=500 + s) for s in range(4)]
+    refs = [oracle_y(y, case) for y in ys]
+    c = synth.chroma(w // 2, h // 2, 8)
+
+    def plane(shape):
+        n = shape[0] * shape[1]
+        p = libc.malloc(n)
+        a = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p)).reshape(shape)
+        return p, a
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        seen = set()
+        first = True
+        for it in range(24):
+            py, ay = plane((h, w)); po, ao = plane((2 * h, 2 * w))
+            pu, au = plane((h // 2, w // 2)); pou, aou = plane((h, w)); pov, aov = plane((h, w))
+            seen.add((py, po))
+            ay[...] = ys[it % 4]; au[...] = c; ao[...] = 0
+            if first:
+                assert R.RNLHandler_SetRes((ay, au, au), (ao, aou, aov)) == 0
+                first = False
+            assert R.RNLHandler_Process((ay, au, au), (ao, aou, aov)) == 0
+            assert np.array_equal(ao, refs[it % 4]), (it, int((ao != refs[it % 4]).sum()))
+            for p in (py, po, pu, pou, pov):
+                libc.free(p)
+        # more live buffers than the cache has entries (48): the oldest registrations are dropped, nothing breaks
+        live = []
+        for it in range(60):
+            py, ay = plane((h, w)); po, ao = plane((2 * h, 2 * w))
+            live.append((py, po))
+            ay[...] = ys[it % 4]
+            pu, au = plane((h // 2, w // 2)); au[...] = c
+            pou, aou = plane((h, w)); pov, aov = plane((h, w))
+            live.append((pu, pou)); live.append((pov, pov))
+            assert R.RNLHandler_Process((ay, au, au), (ao, aou, aov)) == 0
+            assert np.array_equal(ao, refs[it % 4]), ("many buffers", it)
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+        for a, b in live:
+            libc.free(a)
+            if b != a:
+                libc.free(b)

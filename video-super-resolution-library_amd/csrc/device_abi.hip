@@ -223,6 +223,7 @@ struct raisr_hip_ctx {
     uint8_t* d_hash2[2] = {nullptr, nullptr};   // [H][16] second hash of the tail (overlap) columns
     float* d_hr[2] = {nullptr, nullptr};
     void* d_mid = nullptr;                      // two-pass intermediate (sample type), only when the passes differ in size
+    const void* lr0_alias = nullptr;            // set per frame: pass 1 runs at input size on a tightly pitched input plane -> no copy into d_lr[0]
     int passW[2] = {0, 0}, passH[2] = {0, 0};
     GaussW gauss{};
     // device staging for raisr_hip_process_host
@@ -260,6 +261,13 @@ ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch,
     const int gx = gcd_int(sw, dw), gy = gcd_int(sh, dh);
     R.Sx = sw / gx; R.Dx = dw / gx; R.Sy = sh / gy; R.Dy = dh / gy;
     R.tie_even = tie == RAISR_HIP_TIE_HALF_EVEN;
+    {   // 32-bit path of k_resize: upscale (S <= 2 D keeps n + den >= 0), 16-bit divisors, every product below 2^31
+        const long long denx = 2LL * R.Dx, deny = 2LL * R.Dy, den = denx * deny;
+        const bool ok = R.Sx <= 2 * R.Dx && R.Sy <= 2 * R.Dy && denx < 65536 && deny < 65536 && 2 * den < 65536 && sw < (1 << 20) && sh < (1 << 20) &&
+                        2 * den * 65535 + den < (1LL << 31) && (2LL * dw + 1) * R.Sx + denx < (1LL << 31) && (2LL * dh + 1) * R.Sy + deny < (1LL << 31);
+        R.narrow = ok ? 1 : 0;
+        R.rdenx = 1.0f / (float)denx; R.rdeny = 1.0f / (float)deny; R.rden2 = 1.0f / (float)(2 * den);
+    }
     return R;
 }
 
@@ -310,6 +318,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
 template <typename TOut>
 void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
 {
+    const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
     int slot;
@@ -330,16 +339,16 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             const unsigned ntiles = gf.x * gf.y;
             const unsigned npers = ntiles < 1024u ? ntiles : 1024u;          // 4 workgroups per CU resident (LDS), each walks ~ntiles/1024 tiles
             timer_begin(c, "k_hash_ac", s, slot);
-            hipLaunchKernelGGL((k_hash_ac<TOut>), dim3(npers), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->sep, F, c->d_hash[pass], c->d_hash2[pass]);
+            hipLaunchKernelGGL((k_hash_ac<TOut>), dim3(npers), dim3(256), 0, s, (const TOut*)lrp, P, c->sep, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             if (c->fast < 2) {
             timer_begin(c, "k_fix", s, slot);
-            hipLaunchKernelGGL((k_fix_sparse<TOut>), dim3((ntiles + 3u) / 4u), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, F, c->d_hash[pass], c->d_hash2[pass]);
+            hipLaunchKernelGGL((k_fix_sparse<TOut>), dim3((ntiles + 3u) / 4u), dim3(256), 0, s, (const TOut*)lrp, P, F, c->d_hash[pass], c->d_hash2[pass]);
             const unsigned nd = (unsigned)(gf.x * gf.y < 2048u ? gf.x * gf.y : 2048u);
             if (!avx2all)
-                hipLaunchKernelGGL((k_fix_dense<TOut, false>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
+                hipLaunchKernelGGL((k_fix_dense<TOut, false>), dim3(nd), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             else
-                hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
+                hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             }
             if (c->fast && c->model[pass].bank_mfma) {             // the panels are allocated by configure / set_fast (errors reported there)
@@ -353,11 +362,11 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                     timer_begin(c, "k_filter_mfma", s, slot);
 #ifdef RAISR_HIP_DEV                                                  /* profiling aid of a development build (scripts/build_exp.sh dev -DRAISR_HIP_DEV) */
                     static const int mpart = getenv("RAISR_HIP_MF_PART") ? atoi(getenv("RAISR_HIP_MF_PART")) : 0;
-                    if (mpart == 1) hipLaunchKernelGGL((k_filter_mfma<TOut, 1>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
-                    else if (mpart == 2) hipLaunchKernelGGL((k_filter_mfma<TOut, 2>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    if (mpart == 1) hipLaunchKernelGGL((k_filter_mfma<TOut, 1>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    else if (mpart == 2) hipLaunchKernelGGL((k_filter_mfma<TOut, 2>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
                     else
 #endif
-                    hipLaunchKernelGGL((k_filter_mfma<TOut>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
+                    hipLaunchKernelGGL((k_filter_mfma<TOut>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
                     timer_end(c, s, slot);
                 }
             } else if (c->lds_filter && c->cfg.bits <= 10) {      // samples above 10 bits are not exact in binary16: k_filter
@@ -365,12 +374,12 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 const int wh = sp2 ? 41 : 26;
                 const size_t sh16 = (size_t)217 * 128 * 4 + 2 * (size_t)wh * (sp2 ? 286 : 154) * 2 + 4 * 1024;
                 timer_begin(c, "k_filter_lds16", s, slot);
-                if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
-                else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                if (sp2) hipLaunchKernelGGL((k_filter_lds16<TOut, 2>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                else hipLaunchKernelGGL((k_filter_lds16<TOut, 1>), dim3(c->n_cus), dim3(1024), sh16, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
             } else {
                 timer_begin(c, "k_filter", s, slot);
-                hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
+                hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
             }
         } else if (c->fused && c->certify) {
@@ -382,49 +391,50 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
             if (part == 2 && getenv("RAISR_HIP_AC_PATTERN")) P.cert_check = atoi(getenv("RAISR_HIP_AC_PATTERN"));
             if (part == 1)
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             else if (part == 2)
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             else
 #endif
 #ifdef RAISR_EXP_PERSIST
                 if (getenv("RAISR_HIP_PERSIST")) {
                     const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST")));
-                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y);
+                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
+                                       c->n_cus, getenv("RAISR_HIP_PERSIST_SKEW") ? atoi(getenv("RAISR_HIP_PERSIST_SKEW")) : 0);
                 } else
 #endif
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
             timer_begin(c, "k_hashfilter", s, slot);
             if (!avx2all)
-                hipLaunchKernelGGL((k_hashfilter<TOut, false>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+                hipLaunchKernelGGL((k_hashfilter<TOut, false>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
             else
-                hipLaunchKernelGGL((k_hashfilter<TOut, true>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
+                hipLaunchKernelGGL((k_hashfilter<TOut, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else {
             timer_begin(c, "k_hash", s, slot);
             if (!avx2all)
-                hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+                hipLaunchKernelGGL((k_hash<R, TOut, false>), gh, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
             else
-                hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
+                hipLaunchKernelGGL((k_hash<R, TOut, true>), gh, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             timer_begin(c, "k_filter", s, slot);
-            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
+            hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass]);
             timer_end(c, s, slot);
         }
     }
     if (P.randomness) {
         dim3 gb((W + 63) / 64, (H + 3) / 4);
         timer_begin(c, "k_blend_rand", s, slot);
-        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const TOut*)lrp, (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
         timer_end(c, s, slot);
         return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend", s, slot);
-    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
 }
 
@@ -432,6 +442,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
 template <typename TOut>
 void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
 {
+    const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
     const ModelDev& m = c->model[pass];
@@ -453,27 +464,27 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
         if (c->fused) {
             P.write_hash = c->keep_hash_plane;
             timer_begin(c, "k_hashfilter16", s, slot);
-            hipLaunchKernelGGL((k_hashfilter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass], (uint16_t*)c->d_hr[pass]);
+            hipLaunchKernelGGL((k_hashfilter16<TOut>), gh, dim3(256), 0, s, (const TOut*)lrp, P, Q, c->gauss16, c->d_hash[pass], (uint16_t*)c->d_hr[pass]);
             timer_end(c, s, slot);
         } else {
             timer_begin(c, "k_hash16", s, slot);
-            hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, Q, c->gauss16, c->d_hash[pass]);
+            hipLaunchKernelGGL((k_hash16<4, TOut>), gh, dim3(256), 0, s, (const TOut*)lrp, P, Q, c->gauss16, c->d_hash[pass]);
             timer_end(c, s, slot);
             timer_begin(c, "k_filter16", s, slot);
-            hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
+            hipLaunchKernelGGL((k_filter16<TOut>), gh, dim3(256), 0, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, Q, (uint16_t*)c->d_hr[pass]);
             timer_end(c, s, slot);
         }
     }
     if (P.randomness) {
         dim3 gr((W + 63) / 64, (H + 3) / 4);
         timer_begin(c, "k_blend_rand", s, slot);
-        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+        hipLaunchKernelGGL((k_blend_rand<TOut, true>), gr, dim3(256), 0, s, (const TOut*)lrp, (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
         timer_end(c, s, slot);
         return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend16", s, slot);
-    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)c->d_lr[pass], (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
+    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
 }
 
@@ -947,7 +958,9 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
     auto job = [&](auto tag) {
         using T = decltype(tag);
         ResizeParams R0 = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
-        launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
+        // pass 1 at input size (two-pass mode 2, Raisr.cpp:960-975) on a tightly pitched plane: the kernels read it where it lies
+        c->lr0_alias = (g.in_width == c->passW[0] && g.in_height == c->passH[0] && ipe == c->passW[0]) ? d_in : nullptr;
+        if (!c->lr0_alias) launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
         if (g.passes == 1) {
             if (fp16) run_pass16<T>(c, s, 0, d_out, ope); else run_pass<T>(c, s, 0, d_out, ope);
             return;

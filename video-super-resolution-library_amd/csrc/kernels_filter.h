@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ 
 // Experiment: the same tile routine in a persistent grid (4 workgroups per CU walk the tiles in XCD-aware order).
 template <typename T>
 __global__ __launch_bounds__(256, 4) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
-                                                           uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y)
+                                                           uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y,
+                                                           int ncus, int skew_ticks)
 {
     constexpr int TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
@@ -298,6 +299,10 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_acp(const T* __restrict__
     __shared__ uint16_t sList[kListMax];
     __shared__ unsigned sCnt[3];
     const unsigned ntiles = (unsigned)(tiles_x * tiles_y);
+    if (skew_ticks > 0) {                                  // de-phase the workgroups that share a CU (k-th workgroup of a CU starts k * skew later)
+        const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x / (unsigned)ncus) * (unsigned)skew_ticks);
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
 #pragma unroll 1
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int bx, by;

@@ -441,6 +441,9 @@ template <typename TOut>
 __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, const uint16_t* __restrict__ hr,
                                                  PassParams P, Pass16 Q, TOut* __restrict__ out, int out_pitch)
 {
+    // Same shape as k_blend: tile 64 x 16, wave w owns rows [4w, 4w+4), lane = column; LR / HR tiles with a 1-px halo staged in
+    // LDS with every load of a thread in flight before its first LDS write (wave = tile row, no index divisions), and a
+    // 3 x 3 register window sliding down the wave's rows (6 LDS reads per pixel instead of 18).
     constexpr int TW = 64, TH = 16, LW = TW + 2, LH = TH + 2;
     __shared__ float sL[LH * LW];
     __shared__ float sHh[LH * LW];
@@ -448,50 +451,78 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = bx * TW, r0 = by * TH;
-    {   // linear sweep, every lane busy; all LR and HR loads of a thread in flight before the first LDS write
-        constexpr unsigned N = LH * LW, NL = (N + 255u) / 256u;
-        TOut lv[NL];
-        float hv[NL];
-        bool inz[NL];
+    {
+        constexpr int NM = (LH + 3) / 4, REM = LW - 64;
+        static_assert(LH * REM <= 256, "halo columns fit one sweep");
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+        const int gxm = min(max(c0 - 1 + lane, 0), P.W - 1);
+        const bool inxm = gxm >= kMargin && gxm < P.c_final;
+        TOut lv[NM + 1];
+        uint16_t hv[NM + 1];
+        bool inz[NM + 1];
 #pragma unroll
-        for (unsigned it = 0; it < NL; it++) {
-            const unsigned idx = min(threadIdx.x + 256u * it, N - 1u);
-            const int ty = (int)(idx / LW), tx = (int)(idx - (unsigned)ty * LW);
-            const int gy = min(max(r0 - 1 + ty, 0), P.H - 1), gx = min(max(c0 - 1 + tx, 0), P.W - 1);
-            lv[it] = lr[(size_t)gy * P.lr_pitch + gx];
-            inz[it] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
-            hv[it] = inz[it] ? (float)h_bits(hr[(size_t)gy * P.hr_pitch + gx]) : 0.0f;
+        for (int it = 0; it < NM; it++) {
+            const int gy = min(max(r0 - 1 + min(wu + 4 * it, LH - 1), 0), P.H - 1);
+            lv[it] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gxm];
+            inz[it] = inxm && gy >= kMargin && gy < P.H - kMargin;
+            hv[it] = inz[it] ? hr[(unsigned)gy * (unsigned)P.hr_pitch + (unsigned)gxm] : (uint16_t)0;
+        }
+        const int rty = min((int)(threadIdx.x / REM), LH - 1), rtx = 64 + (int)(threadIdx.x % REM);
+        {
+            const int gy = min(max(r0 - 1 + rty, 0), P.H - 1), gx = min(max(c0 - 1 + rtx, 0), P.W - 1);
+            lv[NM] = lr[(unsigned)gy * (unsigned)P.lr_pitch + (unsigned)gx];
+            inz[NM] = gy >= kMargin && gy < P.H - kMargin && gx >= kMargin && gx < P.c_final;
+            hv[NM] = inz[NM] ? hr[(unsigned)gy * (unsigned)P.hr_pitch + (unsigned)gx] : (uint16_t)0;
         }
 #pragma unroll
-        for (unsigned it = 0; it < NL; it++) {
-            const unsigned idx = threadIdx.x + 256u * it;
+        for (int it = 0; it < NM; it++) {
+            const int ty = wu + 4 * it;
             const float L = (float)lv[it];
-            if (idx < N) {
-                sL[idx] = L;
-                sHh[idx] = inz[it] ? hv[it] : L;                                    // HR := LR outside the filtered zone
+            if (ty < LH) {
+                sL[ty * LW + lane] = L;
+                sHh[ty * LW + lane] = inz[it] ? (float)h_bits(hv[it]) : L;               // HR := LR outside the filtered zone
             }
+        }
+        if (threadIdx.x < LH * REM) {
+            const float L = (float)lv[NM];
+            sL[rty * LW + rtx] = L;
+            sHh[rty * LW + rtx] = inz[NM] ? (float)h_bits(hv[NM]) : L;
         }
     }
     __syncthreads();
     const int x = c0 + lane;
     if (x >= P.W) return;
-#pragma unroll 1
+    float l[3][3], h[3][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            l[i + 1][j] = sL[(4 * w + i) * LW + lane + j];
+            h[i + 1][j] = sHh[(4 * w + i) * LW + lane + j];
+        }
+#pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         const int y = r0 + 4 * w + rr;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            l[0][j] = l[1][j]; l[1][j] = l[2][j]; h[0][j] = h[1][j]; h[1][j] = h[2][j];
+            l[2][j] = sL[(4 * w + rr + 2) * LW + lane + j];
+            h[2][j] = sHh[(4 * w + rr + 2) * LW + lane + j];
+        }
         if (y >= P.H) break;
-        const int ty = 4 * w + rr + 1, tx = lane + 1;
-        const float Lc = sL[ty * LW + tx], Hc = sHh[ty * LW + tx];
+        const float Lc = l[1][1], Hc = h[1][1];
         int iv;
         if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
             iv = (int)Lc;
         } else {
             int hd = 0;
 #pragma unroll
-            for (int i = -1; i <= 1; i++)
+            for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int j = -1; j <= 1; j++) {
-                    if (i == 0 && j == 0) continue;
-                    hd += ((sL[(ty + i) * LW + tx + j] < Lc) != (sHh[(ty + i) * LW + tx + j] < Hc));
+                for (int j = 0; j < 3; j++) {
+                    if (i == 1 && j == 1) continue;
+                    hd += ((l[i][j] < Lc) != (h[i][j] < Hc));
                 }
             if (x < Q.c_avx) {
                 const hf weight = (hf)((float)hd * 0.125f);          // hd / 8 exactly

@@ -12,6 +12,8 @@ struct ResizeParams {
     int spitch, dpitch;          // in elements
     int Sx, Dx, Sy, Dy;          // reduced ratios
     int tie_even;
+    int narrow;                  // 1: the 32-bit path of k_resize is exact for this geometry (make_resize)
+    float rdenx, rdeny, rden2;   // 1 / (2 Dx), 1 / (2 Dy), 1 / (2 * 2 Dx * 2 Dy)
 };
 
 __device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0, int& i1, int& f)
@@ -23,12 +25,56 @@ __device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0,
     i1 = min(max(q + 1, 0), size - 1);
 }
 
+// floor(x / d) for 0 <= x < 2^31 and a kernel-uniform divisor 0 < d < 2^16 with rd = 1.0f / d from the host: the fp32 estimate
+// is within one of the quotient (relative error < 2^-22, quotient < 2^31 / d), two compare-and-adjust steps make it exact.
+// (The generic 32-bit division expands to ~30 instructions, the 64-bit one of the wide path below to ~150.)
+__device__ __forceinline__ unsigned div_small(unsigned x, unsigned d, float rd)
+{
+    unsigned q = (unsigned)((float)x * rd);
+    int r = (int)(x - q * d);
+    if (r < 0) { q--; r += (int)d; }
+    if (r < 0) { q--; r += (int)d; }
+    if (r >= (int)d) { q++; r -= (int)d; }
+    if (r >= (int)d) q++;
+    return q;
+}
+
+// axis_tap with n + den >= 0 folded in (d >= 0, S <= 2 D: any upscale): floor(n / den) = floor((n + den) / den) - 1
+__device__ __forceinline__ void axis_tap_small(int d, int S, int D, float rden, int size, int& i0, int& i1, int& f)
+{
+    const unsigned den = 2u * (unsigned)D;
+    const unsigned n1 = (unsigned)((2 * d + 1) * S - D + (int)den);
+    const unsigned q1 = div_small(n1, den, rden);
+    f = (int)(n1 - q1 * den);
+    const int q = (int)q1 - 1;
+    i0 = min(max(q, 0), size - 1);
+    i1 = min(max(q + 1, 0), size - 1);
+}
+
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= R.dw || y >= R.dh) return;
+    if (R.narrow) {
+        // every intermediate fits 32 bits (checked on the host: 2 denx deny 65535 + denx deny < 2^31, S <= 2 D, coordinates < 2^15)
+        int x0, x1, fx, y0, y1, fy;
+        axis_tap_small(x, R.Sx, R.Dx, R.rdenx, R.sw, x0, x1, fx);
+        axis_tap_small(y, R.Sy, R.Dy, R.rdeny, R.sh, y0, y1, fy);
+        const unsigned denx = 2u * (unsigned)R.Dx, deny = 2u * (unsigned)R.Dy;
+        const TIn* r0 = src + (size_t)y0 * R.spitch;
+        const TIn* r1 = src + (size_t)y1 * R.spitch;
+        const unsigned top = (denx - (unsigned)fx) * (unsigned)r0[x0] + (unsigned)fx * (unsigned)r0[x1];
+        const unsigned bot = (denx - (unsigned)fx) * (unsigned)r1[x0] + (unsigned)fx * (unsigned)r1[x1];
+        const unsigned num = (deny - (unsigned)fy) * top + (unsigned)fy * bot;
+        const unsigned den = denx * deny;
+        const unsigned t = 2u * num + den;
+        unsigned q = div_small(t, 2u * den, R.rden2);
+        if (R.tie_even && (t - q * 2u * den == 0u) && (q & 1u)) q--;
+        dst[(size_t)y * R.dpitch + x] = (TOut)q;
+        return;
+    }
     int x0, x1, fx, y0, y1, fy;
     axis_tap(x, R.Sx, R.Dx, R.sw, x0, x1, fx);
     axis_tap(y, R.Sy, R.Dy, R.sh, y0, y1, fy);

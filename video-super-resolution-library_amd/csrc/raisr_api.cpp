@@ -52,6 +52,10 @@ struct State {
     int chromaInH = 0, chromaOutH = 0;
     // plane geometry RNLSetRes configured: RNLProcess refuses frames that differ (the copies are asynchronous DMAs)
     unsigned geo[6][2] = {};                      // {width, height} of inY, inCr, inCb, outY, outCr, outCb
+    raisr_hip_config cfg{};                       // what RNLSetRes configured (the async ring is configured with the same)
+    // asynchronous frames (RNLHandler_Submit / _Collect): a ring of `asyncDepth` lanes over the same models and geometry
+    raisr_hip_stream *ring = nullptr;
+    unsigned asyncDepth = 0;                      // RNLHandler_SetAsyncDepth; 0 = no ring
     bool deviceChosen = false;                    // RNLSetOpenCLContext named a device; otherwise RAISR_HIP_DEVICE / 0
     bool external = false;                        // asm = HIPExternal: plane pointers are device pointers
     void *externalStream = nullptr;               // caller's hipStream_t for external frames (NULL: own stream + wait)
@@ -167,6 +171,61 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
     return RNLErrorNone;
 }
 
+// ---- page-locked caller planes ------------------------------------------------------------------
+// A copy from or to pageable memory is staged by the runtime on the calling thread; a copy on page-locked memory is a DMA the
+// copy engines run next to the kernels.  Hosts like FFmpeg recycle a handful of frame buffers through a pool, so the planes
+// RNLProcess sees are page-locked on first sight and remembered (bounded, least-recently-used entry dropped; everything is
+// unlocked in RNLDeinit).  A stale entry -- the host freed the buffer and the allocator reused the address -- is harmless on
+// this platform: the driver tracks registered user pages with MMU notifiers and re-validates the range
+// (tests/test_gpu_host_api.py::test_registered_planes_survive_free_and_reuse).  RAISR_HIP_PIN=0 turns the cache off.
+struct PinCache {
+    struct Ent { uintptr_t base; size_t bytes; uint64_t stamp; bool ours; bool failed; };
+    std::vector<Ent> ents;
+    uint64_t clock = 0;
+    size_t cap = 48;                                  // > 2 x 3 planes x the deepest pool vf_raisr sees in practice
+    int enabled = -1;
+
+    bool on()
+    {
+        if (enabled < 0) { const char *e = std::getenv("RAISR_HIP_PIN"); enabled = (e && std::atoi(e) == 0) ? 0 : 1; }
+        return enabled == 1;
+    }
+    // page-lock [p, p + bytes) unless an entry already covers it; false = leave it to the pageable path
+    bool pin(const void *p, size_t bytes)
+    {
+        if (!on() || !p || bytes < (size_t)64 * 1024) return false;      // small planes: the registration costs more than it saves
+        const uintptr_t page = 4096, lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+        for (Ent &e : ents)
+            if (e.base <= lo && hi <= e.base + e.bytes) { e.stamp = ++clock; return !e.failed; }
+        if (ents.size() >= cap) {                                         // drop the least recently used entry
+            size_t k = 0;
+            for (size_t i = 1; i < ents.size(); i++) if (ents[i].stamp < ents[k].stamp) k = i;
+            if (ents[k].ours) (void)raisr_hip_host_unregister((void *)ents[k].base);
+            ents.erase(ents.begin() + (long)k);
+        }
+        const int rc = raisr_hip_host_register((void *)lo, hi - lo);
+        // RAISR_HIP_ESTATE: somebody else (the host itself, an earlier overlapping entry) already page-locked the range
+        ents.push_back({lo, hi - lo, ++clock, rc == RAISR_HIP_OK, rc != RAISR_HIP_OK && rc != RAISR_HIP_ESTATE});
+        return !ents.back().failed;
+    }
+    void clear()
+    {
+        for (Ent &e : ents) if (e.ours) (void)raisr_hip_host_unregister((void *)e.base);
+        ents.clear();
+    }
+} gPins;
+
+void pinPlanes(VideoDataType *const pl[6])
+{
+    for (int i = 0; i < 6; i++)
+        if (pl[i] && pl[i]->pData) (void)gPins.pin(pl[i]->pData, (size_t)pl[i]->step * pl[i]->height);
+}
+
+void dropRing()
+{
+    if (G.ring) { raisr_hip_stream_destroy(G.ring); G.ring = nullptr; }      // waits for the frames in flight
+}
+
 void dropExtraBands()
 {
     for (raisr_hip_ctx *c : G.extra) raisr_hip_destroy(c);
@@ -175,6 +234,7 @@ void dropExtraBands()
 
 void dropContext()
 {
+    dropRing();
     dropExtraBands();
     if (G.ctx) { raisr_hip_destroy(G.ctx); G.ctx = nullptr; }
     G.resSet = false;
@@ -364,7 +424,9 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
     cfg.use_pixel_type = G.ratio == 2.0f ? 1 : 0;     // gUsePixelType, Raisr.cpp:1477-1480
     cfg.tie_rule = RAISR_HIP_TIE_HALF_UP;
 
+    G.cfg = cfg;
     // band plan: luma with the pass count's padding, chroma (cheap upscale only) with its own
+    dropRing();
     dropExtraBands();
     G.resSet = false;
     const int want = G.external ? 1 : wantedBands(cfg.out_height);
@@ -428,6 +490,10 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         return RNLErrorUndefined;
     };
     const size_t K = G.yBands.size();
+    if (!G.external) {
+        VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
+        pinPlanes(pl);
+    }
     if (G.external) {
         // planes are device pointers: RAISR on Y and the cheap upscale of both chroma planes without leaving HBM
         if (inCr->step != inCb->step || outCr->step != outCb->step) return RNLErrorBadParameter;
@@ -504,8 +570,81 @@ RNLERRORTYPE RNLDeinit()
     G.externalStream = nullptr;
     G.deviceChosen = false;
     G.device = 0;
+    G.asyncDepth = 0;
+    gPins.clear();
     return RNLErrorNone;
 }
+
+// ---- asynchronous frames (extension; the reference's Process is synchronous, Raisr.cpp:1294-1397) ----------------------------
+// RNLSubmit enqueues a frame on the next lane of a ring (upload, kernels, download: all asynchronous on page-locked planes) and
+// returns; RNLCollect waits for the OLDEST submitted frame.  Same validation and the same bits as RNLProcess; the caller keeps
+// every plane valid and untouched between a frame's Submit and its Collect.
+RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth)
+{
+    if (depth > 16) return RNLErrorBadParameter;
+    if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) return RNLErrorBadParameter;      // collect first
+    dropRing();
+    G.asyncDepth = depth;
+    return RNLErrorNone;
+}
+
+static RNLERRORTYPE checkFrame(VideoDataType *const pl[6])
+{
+    for (int i = 0; i < 6; i++) if (!pl[i] || !pl[i]->pData) return RNLErrorBadParameter;
+    if (!G.inited || !G.resSet || !G.ctx) return RNLErrorBadParameter;
+    const unsigned bps = G.bitDepth == 8 ? 1u : 2u;
+    for (int i = 0; i < 6; i++) {
+        if (i == 2 || i == 5) {
+            if (pl[i]->width != pl[i - 1]->width || pl[i]->height != pl[i - 1]->height) return RNLErrorBadParameter;
+        } else if (pl[i]->width != G.geo[i][0] || pl[i]->height != G.geo[i][1]) return RNLErrorBadParameter;
+        if ((uint64_t)pl[i]->step < (uint64_t)pl[i]->width * bps) return RNLErrorBadParameter;
+    }
+    return RNLErrorNone;
+}
+
+RNLERRORTYPE RNLSubmit(VideoDataType *inY, VideoDataType *inCr, VideoDataType *inCb,
+                       VideoDataType *outY, VideoDataType *outCr, VideoDataType *outCb, BlendingMode blendingMode)
+{
+    VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
+    const RNLERRORTYPE ok = checkFrame(pl);
+    if (ok != RNLErrorNone) return ok;
+    if (blendingMode != CountOfBitsChanged && blendingMode != Randomness) return RNLErrorBadParameter;
+    if (G.external || G.asyncDepth == 0) return RNLErrorBadParameter;           // device-pointer frames are stream-ordered already
+    auto failed = [&](const char *what) {
+        std::cout << "[RAISR ERROR] " << what << ": " << raisr_hip_last_error() << std::endl;
+        return RNLErrorUndefined;
+    };
+    if (!G.ring) {
+        int rc = raisr_hip_stream_create(&G.ring, G.device, (int)G.asyncDepth);
+        if (rc != RAISR_HIP_OK) { G.ring = nullptr; return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : failed("async ring"); }
+        for (unsigned p = 0; p < G.passes && rc == RAISR_HIP_OK; p++) {
+            const PassModel &M = G.model[p];
+            rc = raisr_hip_stream_set_model(G.ring, (int)p, M.bank.data(), (int)M.hashkeys, (int)M.pixelTypes, M.qstr.data(), M.qcoh.data(), (int)G.qAngle);
+        }
+        if (rc == RAISR_HIP_OK) rc = raisr_hip_stream_configure(G.ring, &G.cfg);
+        if (rc != RAISR_HIP_OK) { dropRing(); return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : failed("async ring set-up"); }
+    }
+    if (raisr_hip_stream_in_flight(G.ring) >= raisr_hip_stream_depth(G.ring)) return RNLErrorInsufficientResources;   // ring full: collect first
+    pinPlanes(pl);
+    if (raisr_hip_stream_set_blending(G.ring, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
+    const int rc = raisr_hip_stream_submit(G.ring, inY->pData, inY->step, outY->pData, outY->step,
+                                           inCr->pData, inCr->step, outCr->pData, outCr->step,
+                                           inCb->pData, inCb->step, outCb->pData, outCb->step,
+                                           (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height);
+    return rc != RAISR_HIP_OK ? failed("submit failed") : RNLErrorNone;
+}
+
+RNLERRORTYPE RNLCollect()
+{
+    if (!G.ring || raisr_hip_stream_in_flight(G.ring) == 0) return RNLErrorBadParameter;
+    if (raisr_hip_stream_collect(G.ring) != RAISR_HIP_OK) {
+        std::cout << "[RAISR ERROR] collect failed: " << raisr_hip_last_error() << std::endl;
+        return RNLErrorUndefined;
+    }
+    return RNLErrorNone;
+}
+
+int RNLFramesInFlight() { return G.ring ? raisr_hip_stream_in_flight(G.ring) : 0; }
 
 // ---- C ABI (RaisrHandler.cpp:11-60 in the reference: one-line forwards) -------------------------
 
@@ -540,5 +679,17 @@ RNLERRORTYPE RNLHandler_Deinit(void)
 {
     return RNLDeinit();
 }
+
+RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth) { return RNLSetAsyncDepth(depth); }
+
+RNLERRORTYPE RNLHandler_Submit(VideoDataType *inY, VideoDataType *inU, VideoDataType *inV,
+                               VideoDataType *outY, VideoDataType *outU, VideoDataType *outV, BlendingMode blendingMode)
+{
+    return RNLSubmit(inY, inU, inV, outY, outU, outV, blendingMode);
+}
+
+RNLERRORTYPE RNLHandler_Collect(void) { return RNLCollect(); }
+
+int RNLHandler_FramesInFlight(void) { return RNLFramesInFlight(); }
 
 }  // extern "C"

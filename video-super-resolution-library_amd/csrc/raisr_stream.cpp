@@ -123,6 +123,17 @@ int raisr_hip_stream_set_fast(raisr_hip_stream* s, int level)
     return RAISR_HIP_OK;
 }
 
+// BlendingMode of the frames submitted from now on (a frame's mode is read when its kernels are enqueued)
+int raisr_hip_stream_set_blending(raisr_hip_stream* s, int blending)
+{
+    if (!s) return RAISR_HIP_EINVAL;
+    for (raisr_hip_ctx* c : s->lanes) {
+        const int rc = raisr_hip_set_blending(c, blending);
+        if (rc != RAISR_HIP_OK) return rc;
+    }
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_stream_configure(raisr_hip_stream* s, const raisr_hip_config* cfg)
 {
     if (!s || !cfg) return RAISR_HIP_EINVAL;
@@ -179,7 +190,13 @@ void* raisr_hip_host_alloc(size_t bytes)
     return p;
 }
 void raisr_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
-int raisr_hip_host_register(void* p, size_t bytes) { return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? RAISR_HIP_OK : RAISR_HIP_ERUNTIME; }
+int raisr_hip_host_register(void* p, size_t bytes)
+{
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess) return RAISR_HIP_OK;
+    (void)hipGetLastError();                                                     // a refused registration is not a sticky error
+    return e == hipErrorHostMemoryAlreadyRegistered ? RAISR_HIP_ESTATE : RAISR_HIP_ERUNTIME;
+}
 int raisr_hip_host_unregister(void* p) { return hipHostUnregister(p) == hipSuccess ? RAISR_HIP_OK : RAISR_HIP_ERUNTIME; }
 
 }  // extern "C"

@@ -138,6 +138,9 @@ def lib():
         vp = ctypes.POINTER(VideoDataType)
         L.RNLHandler_SetRes.argtypes = [vp] * 6
         L.RNLHandler_Process.argtypes = [vp] * 6 + [ctypes.c_int]
+        L.RNLHandler_Submit.argtypes = [vp] * 6 + [ctypes.c_int]
+        L.RNLHandler_SetAsyncDepth.argtypes = [ctypes.c_uint]
+        L.raisr_hip_stream_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.RNLHandler_SetOpenCLContext.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         _LIB = L
     return _LIB
@@ -186,6 +189,24 @@ def RNLHandler_SetOpenCLContext(platform_index=0, device_index=0, stream=None):
 
 def RNLHandler_Deinit():
     return lib().RNLHandler_Deinit()
+
+
+def RNLHandler_SetAsyncDepth(depth):
+    return int(lib().RNLHandler_SetAsyncDepth(ctypes.c_uint(depth)))
+
+
+def RNLHandler_Submit(in_planes, out_planes, blending=CountOfBitsChanged):
+    """Asynchronous counterpart of RNLHandler_Process: the numpy planes must stay alive and untouched until the matching Collect."""
+    d = [_vdt(p) for p in list(in_planes) + list(out_planes)]
+    return int(lib().RNLHandler_Submit(*[ctypes.byref(x) for x in d], blending))
+
+
+def RNLHandler_Collect():
+    return int(lib().RNLHandler_Collect())
+
+
+def RNLHandler_FramesInFlight():
+    return int(lib().RNLHandler_FramesInFlight())
 
 
 def _vdt(a):
