@@ -193,6 +193,7 @@ int  raisr_hip_stream_submit(raisr_hip_stream *s,
                              int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h);
 int  raisr_hip_stream_collect(raisr_hip_stream *s);
 int  raisr_hip_stream_in_flight(const raisr_hip_stream *s);
+int  raisr_hip_stream_quiesce(raisr_hip_stream *s);                                      /* wait for every frame in flight, collect none */
 void *raisr_hip_host_alloc(size_t bytes);            /* page-locked host memory for frame planes */
 void raisr_hip_host_free(void *p);
 int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns; RAISR_HIP_ESTATE: (part of) the range is page-locked already */

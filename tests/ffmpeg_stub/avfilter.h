@@ -5,6 +5,7 @@
 #include "libavutil/pixfmt.h"
 #define av_cold
 #define AVERROR(e) (-(e))
+#define AVERROR_EOF (-0x20464f45)
 #define AV_LOG_ERROR 16
 #define AV_LOG_INFO 32
 #define AV_LOG_VERBOSE 40
@@ -20,7 +21,7 @@ struct AVFilterContext; struct AVFilterLink;
 typedef struct AVFilterLink { struct AVFilterContext *src, *dst; int w, h, format; } AVFilterLink;
 typedef struct AVFilterContext { void *priv; AVFilterLink **inputs, **outputs; } AVFilterContext;
 typedef struct AVFilterPad { const char *name; enum AVMediaType type; int (*config_props)(AVFilterLink *);
-    int (*filter_frame)(AVFilterLink *, AVFrame *); } AVFilterPad;
+    int (*filter_frame)(AVFilterLink *, AVFrame *); int (*request_frame)(AVFilterLink *); } AVFilterPad;
 typedef struct AVFilterFormats AVFilterFormats;
 typedef struct AVFilter { const char *name, *description; int priv_size; int (*init)(AVFilterContext *); void (*uninit)(AVFilterContext *);
     const enum AVPixelFormat *pix_fmts; const AVFilterPad *inputs, *outputs; const AVClass *priv_class; int flags; } AVFilter;

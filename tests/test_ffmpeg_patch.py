@@ -32,6 +32,10 @@ def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_pat
     src = (work / "vf_raisr.c").read_text()
     assert 'asm_t = HIP;' in src and '{.str = "hip"}' in src
     assert "if (asm_t == OpenCL)" not in src        # the device hook now runs for every asm value
+    # async=N: Submit / Collect ring with both frames kept alive, drained at EOF and in uninit
+    for needle in ('{"async",', "RNLHandler_SetAsyncDepth(raisr->async)", "RNLHandler_Submit(", "RNLHandler_Collect()",
+                   ".request_frame = request_frame", "ret == AVERROR_EOF && raisr->q_count > 0", "collect_oldest(ctx, 0)"):
+        assert needle in src, needle
     cc = shutil.which("gcc") or shutil.which("cc")
     out = subprocess.run([cc, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wno-unused-variable", "-Wno-declaration-after-statement",
                           "-I", os.path.join(ROOT, "tests", "ffmpeg_stub"), "-I", os.path.join(ROOT, "include"),

@@ -279,6 +279,9 @@ void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, 
     if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
         dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
         hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else if (2 * R.dw == 3 * R.sw && 2 * R.dh == 3 * R.sh) {
+        dim3 grid(((R.dw + 2) / 3 + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize3x2<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (R.dw == R.sw && R.dh == R.sh) {
         dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
         hipLaunchKernelGGL((k_copy<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);

@@ -282,8 +282,11 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ 
 
 #ifdef RAISR_EXP_PERSIST
 // Experiment: the same tile routine in a persistent grid (4 workgroups per CU walk the tiles in XCD-aware order).
+#ifndef RAISR_EXP_PERSIST_WGS
+#define RAISR_EXP_PERSIST_WGS 4
+#endif
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+__global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                            uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y,
                                                            int ncus, int skew_ticks)
 {
@@ -311,7 +314,11 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_acp(const T* __restrict__
         asm volatile("" : "+v"(tid));                      // opaque per tile: keeps the tile routine's lane-dependent set-up inside the loop
         __builtin_assume(tid < 256u);                      // (hoisted, it costs 52 spilled registers per lane)
         hashfilter_ac_tile<T, 0, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, tid);
+#ifdef RAISR_EXP_PERSIST_LDSBAR
+        lds_barrier();                                     // every wave is done with this tile's LDS (the HR stores stay in flight)
+#else
         __syncthreads();                                   // every wave is done with this tile's LDS
+#endif
     }
 }
 #endif

@@ -180,80 +180,92 @@ __device__ __attribute__((noinline)) int hash_px16_generic(hf a, hf b, hf d, con
 // ------------------------------------------------------------------------------------------------
 // hash16_phase: one tile's tensor + hash once its LR window (origin (r0-6, c0-6), row stride LW) is in sL; returns the
 // lane's R hashes (0xFF = pixel not filtered).
+// Two pixel rows per packed register: the gradient tile holds VERTICAL pairs, entry (t, x) = {(gx[t], gx[t+1]), (gy[t], gy[t+1])}
+// (8 bytes), so that rows j and j + 1 of a lane's four pixels share every instruction of a tap:
+//   PX = X * W;  A2 = fma(PX, X, A2);  B2 = fma(PX, Y, B2);  PY = Y * W;  D2 = fma(PY, Y, D2)        (5 v_pk_*_f16 per 2 pixels)
+// -- per pixel the operations and their order are those of the reference; only the packing differs (round 2 packed (gx, gy)
+// of ONE pixel and spent a scalar v_fma_f16 plus a half-extract on B: 3.3 instructions per pixel and tap).
 template <int R, int LW>
-__device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& Q, const GaussW16& gw, const hf* sL, hf2* sG,
+__device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& Q, const GaussW16& gw, const hf* sL, uint2* sG,
                                              const uint16_t* sTab, int c0, int r0, unsigned (&hA)[R])
 {
+    static_assert(R == 4, "two row pairs per lane");
     constexpr int TH = 4 * R;
-    constexpr int GW_ = 74, GH = TH + 10;
+    constexpr int GW_ = 74, GH = TH + 9;     // pair rows t = 0 .. TH + 8 (pair t covers gradient rows t and t + 1)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
         const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
-        const hf gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
-        const hf gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
-        sG[idx] = (hf2){gxv, gyv};
+        const hf* c = sL + ty * LW + tx + 1;                 // column of the vertical differences
+        const hf gx0 = c[2 * LW] - c[0], gx1 = c[3 * LW] - c[LW];
+        const hf gy0 = c[LW + 1] - c[LW - 1], gy1 = c[2 * LW + 1] - c[2 * LW - 1];
+        sG[idx] = make_uint2(__builtin_bit_cast(uint32_t, (hf2){gx0, gx1}), __builtin_bit_cast(uint32_t, (hf2){gy0, gy1}));
     }
     __syncthreads();
 
-    hf2 curAD[R], holdAD[R], t1AD[R];
-    hf curB[R], holdB[R], t1B[R];
+    hf2 curA[2], curB[2], curD[2], holdA[2], holdB[2], holdD[2], t1A[2], t1B[2], t1D[2];
+    const hf2 z2 = {(hf)0.f, (hf)0.f};
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-        curAD[j] = holdAD[j] = t1AD[j] = (hf2){(hf)0.f, (hf)0.f};
-        curB[j] = holdB[j] = t1B[j] = (hf)0.f;
-    }
+    for (int p = 0; p < 2; p++) curA[p] = curB[p] = curD[p] = holdA[p] = holdB[p] = holdD[p] = t1A[p] = t1B[p] = t1D[p] = z2;
+    // the column's 11 weights sit in SGPRs; the NEXT column's are fetched (scalar loads from the kernel arguments) while this
+    // column's 110 packed operations run, instead of at the top of the iteration with nothing to hide their latency
+    uint32_t wk[11], wn[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) wk[i] = gw.wT[c_col_order[0]][i];
 #pragma unroll 1
     for (int kk = 0; kk < 11; kk++) {
         const int k = c_col_order[kk];
-        hf2 g[R + 10];
+        const int kn = c_col_order[kk < 10 ? kk + 1 : 10];
 #pragma unroll
-        for (int t = 0; t < R + 10; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
-        hf2 AD[R];
-        hf B[R];
+        for (int i = 0; i < 11; i++) wn[i] = gw.wT[kn][i];
+        uint2 g[13];
 #pragma unroll
-        for (int j = 0; j < R; j++) { AD[j] = (hf2){(hf)0.f, (hf)0.f}; B[j] = (hf)0.f; }
+        for (int t = 0; t < 13; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
+        hf2 A[2], B[2], D[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) A[p] = B[p] = D[p] = z2;
 #pragma unroll
         for (int i = 0; i < 11; i++) {
-            const hf2 w2 = __builtin_bit_cast(hf2, gw.wT[k][i]);
+            const hf2 w2 = __builtin_bit_cast(hf2, wk[i]);
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const hf2 gg = g[i + j];
-                const hf2 pq = gg * w2;
-                AD[j] = __builtin_elementwise_fma(pq, gg, AD[j]);
-                B[j] = __builtin_fmaf16(pq.x, gg.y, B[j]);
+            for (int p = 0; p < 2; p++) {
+                const hf2 X = __builtin_bit_cast(hf2, g[i + 2 * p].x), Y = __builtin_bit_cast(hf2, g[i + 2 * p].y);
+                const hf2 PX = X * w2;
+                A[p] = __builtin_elementwise_fma(PX, X, A[p]);
+                B[p] = __builtin_elementwise_fma(PX, Y, B[p]);
+                const hf2 PY = Y * w2;
+                D[p] = __builtin_elementwise_fma(PY, Y, D[p]);
             }
         }
         const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
-        if (start) {
 #pragma unroll
-            for (int j = 0; j < R; j++) { curAD[j] = AD[j]; curB[j] = B[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < R; j++) { curAD[j] = curAD[j] + AD[j]; curB[j] = curB[j] + B[j]; }
+        for (int p = 0; p < 2; p++) {
+            if (start) { curA[p] = A[p]; curB[p] = B[p]; curD[p] = D[p]; }
+            else { curA[p] = curA[p] + A[p]; curB[p] = curB[p] + B[p]; curD[p] = curD[p] + D[p]; }
+            if (kk == 2 || kk == 8) { holdA[p] = curA[p]; holdB[p] = curB[p]; holdD[p] = curD[p]; }
+            if (kk == 5) { t1A[p] = holdA[p] + curA[p]; t1B[p] = holdB[p] + curB[p]; t1D[p] = holdD[p] + curD[p]; }
         }
-        if (kk == 2 || kk == 8) {
 #pragma unroll
-            for (int j = 0; j < R; j++) { holdAD[j] = curAD[j]; holdB[j] = curB[j]; }
-        }
-        if (kk == 5) {
-#pragma unroll
-            for (int j = 0; j < R; j++) { t1AD[j] = holdAD[j] + curAD[j]; t1B[j] = holdB[j] + curB[j]; }
-        }
+        for (int i = 0; i < 11; i++) wk[i] = wn[i];
     }
 
     const int c = c0 + lane;
     const HashQ16 HQ = {Q.qangle, Q.qs0, Q.qs1, Q.qc0, Q.qc1};
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-        const int r = r0 + w * R + j;
-        const hf2 ad = (holdAD[j] + curAD[j]) + t1AD[j];
-        const hf bb = (holdB[j] + curB[j]) + t1B[j];
-        // straight-line for every pixel of the lane (the four chains interleave); out-of-zone pixels are masked afterwards
-        const hf a = h_scale_f32(ad.x, Q.nf), b = h_scale_f32(bb, Q.nf), d = h_scale_f32(ad.y, Q.nf);
-        bool rare = false;
-        unsigned h = (unsigned)hash_px16_impl<true>(a, b, d, HQ, sTab, rare);
-        if (rare) h = (unsigned)hash_px16_generic(a, b, d, HQ, sTab);
-        hA[j] = (r < P.H - kMargin && c < P.c_final) ? h : 0xFFu;
+    for (int p = 0; p < 2; p++) {
+        const hf2 a2 = (holdA[p] + curA[p]) + t1A[p];
+        const hf2 b2 = (holdB[p] + curB[p]) + t1B[p];
+        const hf2 d2 = (holdD[p] + curD[p]) + t1D[p];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int j = 2 * p + e;
+            const int r = r0 + w * R + j;
+            // straight-line for every pixel of the lane (the four chains interleave); out-of-zone pixels are masked afterwards
+            const hf a = h_scale_f32(e ? a2.y : a2.x, Q.nf), b = h_scale_f32(e ? b2.y : b2.x, Q.nf), d = h_scale_f32(e ? d2.y : d2.x, Q.nf);
+            bool rare = false;
+            unsigned h = (unsigned)hash_px16_impl<true>(a, b, d, HQ, sTab, rare);
+            if (rare) h = (unsigned)hash_px16_generic(a, b, d, HQ, sTab);
+            hA[j] = (r < P.H - kMargin && c < P.c_final) ? h : 0xFFu;
+        }
     }
 }
 
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
     constexpr int TH = 4 * R;
     constexpr int LW = 76, LH = TH + 12;
     __shared__ hf sL[LH * LW];
-    __shared__ hf2 sG[(TH + 10) * 74];
+    __shared__ uint2 sG[(TH + 9) * 74];
     __shared__ uint16_t sTab[3072];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
     constexpr int R = 4, TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12;
     __shared__ hf sL[LH * LW];
-    __shared__ hf2 sG[(TH + 10) * 74];
+    __shared__ uint2 sG[(TH + 9) * 74];
     __shared__ uint16_t sTab[3072];
     __shared__ uint8_t sH[TH * TW];          // rows [4w, 4w+4) are written and read by wave w only: no barrier between the stages
 

@@ -134,6 +134,42 @@ __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, T
     }
 }
 
+// 3:2 special case (the reference's 1.5x models): n = 4 d - 1 over den = 6 per axis, so output d = 3 m + e reads sources
+// 2 m - 1 + e and 2 m + e with weights {1,5}, {3,3}, {5,1} (/6) for e = 0, 1, 2; out = floor((2 num + 36) / 72) [half-up].
+// One thread produces 3 adjacent output pixels of one row from 2 x 4 source samples; same arithmetic as k_resize.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
+{
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m = bx * 64 + (threadIdx.x & 63);               // group of 3 output columns
+    const int y = by * 4 + (threadIdx.x >> 6);
+    const int x0 = 3 * m;
+    if (x0 >= R.dw || y >= R.dh) return;
+    const int ny = y / 3, ey = y - 3 * ny;                    // (division by a constant: multiply-high)
+    const int ya = min(max(2 * ny - 1 + ey, 0), R.sh - 1), yb = min(2 * ny + ey, R.sh - 1);
+    const unsigned fy = 5u - 2u * (unsigned)ey, gy = 6u - fy; // weights of yb and ya
+    const TIn* ra = src + (size_t)ya * R.spitch;
+    const TIn* rb = src + (size_t)yb * R.spitch;
+    unsigned v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = min(max(2 * m - 1 + i, 0), R.sw - 1);
+        v[i] = gy * (unsigned)ra[c] + fy * (unsigned)rb[c];
+    }
+    TOut* d = dst + (size_t)y * R.dpitch + x0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        if (x0 + e >= R.dw) break;
+        const unsigned fx = 5u - 2u * (unsigned)e;
+        const unsigned num = (6u - fx) * v[e] + fx * v[e + 1];           // <= 36 * 65535
+        const unsigned t = 2u * num + 36u;
+        unsigned q = t / 72u;
+        if (R.tie_even && t - 72u * q == 0u && (q & 1u)) q--;
+        d[e] = (TOut)q;
+    }
+}
+
 // same-size case of the cheap upscale (two-pass mode 2 runs pass 1 at input size, Raisr.cpp:960-975): widen/copy
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)

@@ -174,13 +174,19 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
 // ---- page-locked caller planes ------------------------------------------------------------------
 // A copy from or to pageable memory is staged by the runtime on the calling thread; a copy on page-locked memory is a DMA the
 // copy engines run next to the kernels.  Hosts like FFmpeg recycle a handful of frame buffers through a pool, so the planes
-// RNLProcess sees are page-locked on first sight and remembered (bounded, least-recently-used entry dropped; everything is
-// unlocked in RNLDeinit).  A stale entry -- the host freed the buffer and the allocator reused the address -- is harmless on
-// this platform: the driver tracks registered user pages with MMU notifiers and re-validates the range
-// (tests/test_gpu_host_api.py::test_registered_planes_survive_free_and_reuse).  RAISR_HIP_PIN=0 turns the cache off.
+// RNLProcess sees are page-locked on first sight and remembered (bounded, least-recently-used region dropped; everything is
+// unlocked in RNLDeinit).  Registration works on whole pages, and the runtime refuses a copy whose host range is only PARTLY
+// inside a registered region -- so regions are kept disjoint and a plane that touches registered pages without lying inside
+// one region gets the union of everything it touches registered as ONE region (after waiting for the frames in flight, whose
+// copies may use the regions being replaced).  A stale region -- the host freed the buffer and the allocator reused the
+// address -- is harmless on this platform: the driver tracks registered user pages with MMU notifiers and re-validates the
+// range (tests/test_gpu_host_api.py::test_registered_planes_survive_free_and_reuse).  RAISR_HIP_PIN=0 turns the cache off.
+void quiesceDevice();
+
 struct PinCache {
-    struct Ent { uintptr_t base; size_t bytes; uint64_t stamp; bool ours; bool failed; };
-    std::vector<Ent> ents;
+    struct Ent { uintptr_t lo, hi; uint64_t stamp; bool ours; };     // [lo, hi): one registered region (ours: we unlock it)
+    std::vector<Ent> ents;                                            // pairwise disjoint
+    std::vector<std::pair<uintptr_t, uintptr_t>> refused;             // ranges the runtime would not register: not asked again
     uint64_t clock = 0;
     size_t cap = 48;                                  // > 2 x 3 planes x the deepest pool vf_raisr sees in practice
     int enabled = -1;
@@ -190,35 +196,62 @@ struct PinCache {
         if (enabled < 0) { const char *e = std::getenv("RAISR_HIP_PIN"); enabled = (e && std::atoi(e) == 0) ? 0 : 1; }
         return enabled == 1;
     }
-    // page-lock [p, p + bytes) unless an entry already covers it; false = leave it to the pageable path
-    bool pin(const void *p, size_t bytes)
+    void drop(size_t k)
     {
-        if (!on() || !p || bytes < (size_t)64 * 1024) return false;      // small planes: the registration costs more than it saves
-        const uintptr_t page = 4096, lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
-        for (Ent &e : ents)
-            if (e.base <= lo && hi <= e.base + e.bytes) { e.stamp = ++clock; return !e.failed; }
-        if (ents.size() >= cap) {                                         // drop the least recently used entry
+        if (ents[k].ours) (void)raisr_hip_host_unregister((void *)ents[k].lo);
+        ents.erase(ents.begin() + (long)k);
+    }
+    void pin(const void *p, size_t bytes)
+    {
+        if (!on() || !p || !bytes) return;
+        const uintptr_t page = 4096;
+        uintptr_t lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+        std::vector<size_t> hit;
+        for (size_t i = 0; i < ents.size(); i++)
+            if (ents[i].hi > lo && ents[i].lo < hi) hit.push_back(i);
+        if (hit.size() == 1 && ents[hit[0]].lo <= lo && hi <= ents[hit[0]].hi) { ents[hit[0]].stamp = ++clock; return; }
+        if (hit.empty() && bytes < (size_t)64 * 1024) return;             // a small plane on pages nobody locked: the pageable path is fine
+        for (const auto &r : refused) if (r.first == lo && r.second == hi) return;
+        if (!hit.empty()) {
+            // the plane straddles registered pages: replace the regions it touches by their union with the plane
+            for (size_t i : hit) if (!ents[i].ours) return;               // somebody else's registration: nothing we can merge
+            quiesceDevice();
+            for (size_t k = hit.size(); k-- > 0;) {
+                lo = ents[hit[k]].lo < lo ? ents[hit[k]].lo : lo;
+                hi = ents[hit[k]].hi > hi ? ents[hit[k]].hi : hi;
+                drop(hit[k]);
+            }
+        }
+        while (ents.size() >= cap) {                                      // drop the least recently used region
             size_t k = 0;
             for (size_t i = 1; i < ents.size(); i++) if (ents[i].stamp < ents[k].stamp) k = i;
-            if (ents[k].ours) (void)raisr_hip_host_unregister((void *)ents[k].base);
-            ents.erase(ents.begin() + (long)k);
+            quiesceDevice();
+            drop(k);
         }
         const int rc = raisr_hip_host_register((void *)lo, hi - lo);
-        // RAISR_HIP_ESTATE: somebody else (the host itself, an earlier overlapping entry) already page-locked the range
-        ents.push_back({lo, hi - lo, ++clock, rc == RAISR_HIP_OK, rc != RAISR_HIP_OK && rc != RAISR_HIP_ESTATE});
-        return !ents.back().failed;
+        if (rc == RAISR_HIP_OK) ents.push_back({lo, hi, ++clock, true});
+        else if (rc == RAISR_HIP_ESTATE) ents.push_back({lo, hi, ++clock, false});      // page-locked by the host itself
+        else if (refused.size() < 256) refused.emplace_back(lo, hi);
     }
     void clear()
     {
-        for (Ent &e : ents) if (e.ours) (void)raisr_hip_host_unregister((void *)e.base);
-        ents.clear();
+        for (Ent &e : ents) if (e.ours) (void)raisr_hip_host_unregister((void *)e.lo);
+        ents.clear(); refused.clear();
     }
 } gPins;
 
 void pinPlanes(VideoDataType *const pl[6])
 {
     for (int i = 0; i < 6; i++)
-        if (pl[i] && pl[i]->pData) (void)gPins.pin(pl[i]->pData, (size_t)pl[i]->step * pl[i]->height);
+        if (pl[i] && pl[i]->pData) gPins.pin(pl[i]->pData, (size_t)pl[i]->step * pl[i]->height);
+}
+
+// everything this library has enqueued is done (frames of the ring stay "in flight" for the caller: Collect returns at once)
+void quiesceDevice()
+{
+    if (G.ctx) (void)raisr_hip_synchronize(G.ctx);
+    for (raisr_hip_ctx *c : G.extra) (void)raisr_hip_synchronize(c);
+    if (G.ring) (void)raisr_hip_stream_quiesce(G.ring);
 }
 
 void dropRing()

@@ -182,6 +182,17 @@ int raisr_hip_stream_collect(raisr_hip_stream* s)
 
 int raisr_hip_stream_in_flight(const raisr_hip_stream* s) { return s ? (int)(s->head - s->tail) : 0; }
 
+// Wait until every submitted frame is complete WITHOUT collecting any (the frames stay in flight for the caller; their collects
+// return at once): what a host does before it unpins or frees memory the frames in flight may still be copied from or to.
+int raisr_hip_stream_quiesce(raisr_hip_stream* s)
+{
+    if (!s) return RAISR_HIP_EINVAL;
+    int rc = RAISR_HIP_OK;
+    for (size_t i = 0; i < s->lanes.size(); i++)
+        if (s->busy[i]) { const int r = raisr_hip_synchronize(s->lanes[i]); if (rc == RAISR_HIP_OK) rc = r; }
+    return rc;
+}
+
 // Page-locked host memory for frame planes (what makes the copies of a stream asynchronous).
 void* raisr_hip_host_alloc(size_t bytes)
 {
