@@ -121,6 +121,33 @@ def _u16(a):
     return np.ascontiguousarray(a, dtype=np.uint16)
 
 
+_LIB512 = None
+
+
+def lib512():
+    """The AVX-512 build (it alone carries the hand-vectorised twin raisr_oracle_avx512.c), or None where the host cannot run it."""
+    global _LIB512
+    if _LIB512 is None and _host_has_avx512():
+        so = os.path.join(_HERE, "libraisr_oracle_avx512.so")
+        if not os.path.exists(so):
+            build()
+        _LIB512 = ctypes.CDLL(so)
+    return _LIB512
+
+
+def process_y_intrinsics(plane, out_w, out_h, p1, p2=None, passes=1, mode=1, tie=TIE_HALF_UP):
+    """process_y through ora512_process_y (own AVX-512 intrinsics; same bits as process_y by construction and by test)."""
+    L = lib512()
+    if L is None:
+        raise RuntimeError("this host does not execute AVX-512")
+    src = _u16(plane)
+    h, w = src.shape
+    out = np.zeros((out_h, out_w), dtype=np.uint16)
+    L.ora512_process_y(src.ctypes.data_as(ctypes.c_void_p), w, h, out.ctypes.data_as(ctypes.c_void_p), out_w, out_h,
+                       passes, mode, ctypes.byref(p1), ctypes.byref(p2 if p2 is not None else p1), tie)
+    return out
+
+
 def resize(plane, out_w, out_h, tie=TIE_HALF_UP):
     src = _u16(plane)
     h, w = src.shape

@@ -195,6 +195,11 @@ struct raisr_hip_ctx {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_done = nullptr;
     bool done_pending = false;
     bool legacy_pending = false;               // ring context that took the two-stream branch of process_host_async (rows != NULL)
+    // bands of one frame on several contexts (raisr_hip_set_after): this context's Y kernels start when the previous band's are
+    // done, so that the bands' kernels run one after the other while band k's download overlaps band k+1's kernels
+    raisr_hip_ctx* after = nullptr;
+    hipEvent_t ev_kern = nullptr;
+    bool ev_kern_valid = false;
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
@@ -403,7 +408,15 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 if (getenv("RAISR_HIP_PERSIST")) {
                     const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST")));
                     hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
-                                       c->n_cus, getenv("RAISR_HIP_PERSIST_SKEW") ? atoi(getenv("RAISR_HIP_PERSIST_SKEW")) : 0);
+                                       c->n_cus, getenv("RAISR_HIP_PERSIST_SKEW") ? atoi(getenv("RAISR_HIP_PERSIST_SKEW")) : 0,
+                                       (unsigned*)nullptr);
+                } else if (getenv("RAISR_HIP_PERSIST_DYN")) {
+                    static unsigned* ctr = nullptr;         // experiment only: one set of counters, one lane
+                    if (!ctr) (void)hipMalloc((void**)&ctr, 16 * sizeof(unsigned));
+                    (void)hipMemsetAsync(ctr, 0, 16 * sizeof(unsigned), s);
+                    const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST_DYN")));
+                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
+                                       c->n_cus, 0, ctr);
                 } else
 #endif
                 hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
@@ -675,6 +688,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->ev_kern) (void)hipEventDestroy(c->ev_kern);
     if (c->own_stream) { c->stream = c->own_stream; c->own_stream = nullptr; }
     if (c->d_gauss) (void)hipFree(c->d_gauss);
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
@@ -1032,6 +1046,17 @@ int raisr_hip_synchronize(raisr_hip_ctx* c)
     return RAISR_HIP_OK;
 }
 
+// Order this context's Y kernels (host-plane entry) after those of `prev` (NULL: no ordering).  Both contexts on one device.
+int raisr_hip_set_after(raisr_hip_ctx* c, raisr_hip_ctx* prev)
+{
+    if (!c || c == prev) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (prev && prev->device != c->device) return fail(RAISR_HIP_EINVAL, "contexts on different devices");
+    HIP_TRY(hipSetDevice(c->device));
+    if (prev && !prev->ev_kern) HIP_TRY(hipEventCreateWithFlags(&prev->ev_kern, hipEventDisableTiming));
+    c->after = prev;
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_use_streams(raisr_hip_ctx* c, void* compute, void* upload, void* download)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
@@ -1204,8 +1229,10 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
         if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
             HIP_TRY(copy_plane(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
+        if (c->after && c->after->ev_kern_valid) HIP_TRY(hipStreamWaitEvent(s, c->after->ev_kern, 0));
         int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
         if (rc) return rc;
+        if (c->ev_kern) { HIP_TRY(hipEventRecord(c->ev_kern, s)); c->ev_kern_valid = true; }
         if (chroma) {
             HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                            uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y,
-                                                           int ncus, int skew_ticks)
+                                                           int ncus, int skew_ticks, unsigned* __restrict__ tile_ctr)
 {
     constexpr int TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
@@ -306,10 +306,24 @@ __global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(c
         const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x / (unsigned)ncus) * (unsigned)skew_ticks);
         while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
     }
+    __shared__ unsigned sTile;
+    const unsigned xcd = blockIdx.x & 7u, n8 = ntiles & ~7u, per = n8 >> 3;
 #pragma unroll 1
-    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (unsigned t = blockIdx.x; ; t += gridDim.x) {
         int bx, by;
-        xcd_tile_of(t, (unsigned)tiles_x, ntiles, bx, by);
+        if (tile_ctr) {                                    // dynamic: the next tile of this XCD's strip (one counter per XCD)
+            if (threadIdx.x == 0) sTile = atomicAdd(&tile_ctr[xcd], 1u);
+            __syncthreads();
+            const unsigned j = sTile;
+            unsigned u;
+            if (j < per) u = xcd * per + j;
+            else if (j == per && n8 + xcd < ntiles) u = n8 + xcd;
+            else break;
+            by = (int)(u / (unsigned)tiles_x); bx = (int)(u - (unsigned)by * (unsigned)tiles_x);
+        } else {
+            if (t >= ntiles) break;
+            xcd_tile_of(t, (unsigned)tiles_x, ntiles, bx, by);
+        }
         unsigned tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                      // opaque per tile: keeps the tile routine's lane-dependent set-up inside the loop
         __builtin_assume(tid < 256u);                      // (hoisted, it costs 52 spilled registers per lane)

@@ -13,6 +13,7 @@
 // State is one process-global instance, as in the reference (Library/Raisr_globals.h:140-203).
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -196,9 +197,15 @@ struct PinCache {
         if (enabled < 0) { const char *e = std::getenv("RAISR_HIP_PIN"); enabled = (e && std::atoi(e) == 0) ? 0 : 1; }
         return enabled == 1;
     }
+    int debug = -1;
+    void log(const char *what, uintptr_t lo, uintptr_t hi, int rc)
+    {
+        if (debug < 0) debug = std::getenv("RAISR_HIP_PIN_DEBUG") ? 1 : 0;
+        if (debug) std::fprintf(stderr, "[raisr pin] %s [%#zx, %#zx) %zu KB -> %d (%zu regions)\n", what, (size_t)lo, (size_t)hi, (size_t)(hi - lo) >> 10, rc, ents.size());
+    }
     void drop(size_t k)
     {
-        if (ents[k].ours) (void)raisr_hip_host_unregister((void *)ents[k].lo);
+        if (ents[k].ours) { const int rc = raisr_hip_host_unregister((void *)ents[k].lo); log("unregister", ents[k].lo, ents[k].hi, rc); }
         ents.erase(ents.begin() + (long)k);
     }
     void pin(const void *p, size_t bytes)
@@ -229,6 +236,7 @@ struct PinCache {
             drop(k);
         }
         const int rc = raisr_hip_host_register((void *)lo, hi - lo);
+        log(hit.empty() ? "register" : "register union", lo, hi, rc);
         if (rc == RAISR_HIP_OK) ents.push_back({lo, hi, ++clock, true});
         else if (rc == RAISR_HIP_ESTATE) ents.push_back({lo, hi, ++clock, false});      // page-locked by the host itself
         else if (refused.size() < 256) refused.emplace_back(lo, hi);
@@ -483,6 +491,13 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
                 ctx = nullptr;
                 int rc = raisr_hip_create(&ctx, G.device);
                 if (rc == RAISR_HIP_OK) { G.extra.push_back(ctx); rc = uploadModels(ctx); }
+                if (rc != RAISR_HIP_OK) return failed(rc);
+            }
+            if (k > 0 && !(std::getenv("RAISR_HIP_BAND_CHAIN") && std::atoi(std::getenv("RAISR_HIP_BAND_CHAIN")) == 0)) {
+                // band k's kernels after band k-1's: the bands' kernels then run back to back and every band's download
+                // overlaps the next band's kernels (unordered, the bands share the GPU and all finish -- and download -- together)
+                raisr_hip_ctx *prev = k == 1 ? G.ctx : G.extra[(size_t)k - 2];
+                const int rc = raisr_hip_set_after(ctx, prev);
                 if (rc != RAISR_HIP_OK) return failed(rc);
             }
             raisr_hip_config sub = cfg;
