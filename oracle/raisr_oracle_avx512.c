@@ -217,12 +217,57 @@ static inline void tensor16(const float *GX, const float *GY, size_t stride, int
 }
 
 /* ---- DotProdPatch: patch rows r-5..r+5, columns c-5..c+5 of L against one padded bank row -------------------------------- */
-static inline float dot121(const float *L, size_t stride, int r, int c, const float *f, float *pb /* [128], pb[121..127] == 0 */)
+/* The reference stores the 11 patch rows into a 128-float buffer and reloads it as 8 vectors (Raisr_AVX512.cpp:116-117); here the
+ * 8 vectors of taps 16 ch .. 16 ch + 15 are permuted straight out of the 11 row registers (a reload right after 44-byte stores
+ * cannot be store-forwarded).  Tap k lives in row k / 11, column k % 11; a chunk spans two or three rows. */
+#define DOT_GROUP 4                   /* pixels served by one set of 11 row loads: 16 floats per row = columns c-5 .. c+10 */
+static __m512i PIDX[DOT_GROUP][8][2]; /* per pixel of the group and chunk: indices into the first two rows (permutex2var) / the third row */
+static __mmask16 PMASK3[8];           /* lanes taken from the third row */
+static int PROW[8][3];
+static int perm_ready;
+
+static void init_perm(void)
+{
+    if (perm_ready) return;
+    for (int sh = 0; sh < DOT_GROUP; sh++)
+        for (int ch = 0; ch < 8; ch++) {
+            int32_t i1[16] = {0}, i2[16] = {0};
+            int ra = (16 * ch) / PATCH, rb = ra + 1, rc = ra + 2;
+            __mmask16 m3 = 0;
+            for (int l = 0; l < 16; l++) {
+                const int k = 16 * ch + l;
+                if (k >= TAPS) { i1[l] = 0; continue; }             /* padding lanes: any finite sample, the coefficient is +0 */
+                const int row = k / PATCH, col = k % PATCH + sh;
+                if (row == ra) i1[l] = col;
+                else if (row == rb) i1[l] = 16 + col;
+                else { i2[l] = col; m3 |= (__mmask16)(1u << l); }
+            }
+            if (rb > PATCH - 1) rb = PATCH - 1;
+            if (rc > PATCH - 1) rc = PATCH - 1;
+            PROW[ch][0] = ra; PROW[ch][1] = rb; PROW[ch][2] = rc;
+            PIDX[sh][ch][0] = _mm512_loadu_si512(i1); PIDX[sh][ch][1] = _mm512_loadu_si512(i2);
+            PMASK3[ch] = m3;
+        }
+    perm_ready = 1;
+}
+
+/* the 11 window rows of pixels c .. c + DOT_GROUP - 1 of row r */
+static inline void dot_rows(const float *L, size_t stride, int r, int c, __m512 R[PATCH])
 {
     const float *p = L + (size_t)(r - PM) * stride + (c - PM);
-    for (int i = 0; i < PATCH; i++) _mm512_mask_storeu_ps(pb + PATCH * i, 0x07FF, _mm512_loadu_ps(p + (size_t)i * stride));
-    __m512 acc = _mm512_mul_ps(_mm512_load_ps(pb), _mm512_load_ps(f));
-    for (int ch = 1; ch < 8; ch++) acc = _mm512_fmadd_ps(_mm512_load_ps(pb + 16 * ch), _mm512_load_ps(f + 16 * ch), acc);
+    for (int i = 0; i < PATCH; i++) R[i] = _mm512_loadu_ps(p + (size_t)i * stride);
+}
+
+/* pixel c + sh of the group whose rows are in R, against one padded bank row */
+static inline float dot121(const __m512 R[PATCH], int sh, const float *f)
+{
+    __m512 acc = _mm512_setzero_ps();
+    for (int ch = 0; ch < 8; ch++) {
+        __m512 v = _mm512_permutex2var_ps(R[PROW[ch][0]], PIDX[sh][ch][0], R[PROW[ch][1]]);
+        if (PMASK3[ch]) v = _mm512_mask_permutexvar_ps(v, PMASK3[ch], PIDX[sh][ch][1], R[PROW[ch][2]]);
+        const __m512 fv = _mm512_load_ps(f + 16 * ch);
+        acc = ch == 0 ? _mm512_mul_ps(v, fv) : _mm512_fmadd_ps(v, fv, acc);
+    }
     const __m256 t = _mm256_add_ps(_mm512_castps512_ps256(acc), _mm512_extractf32x8_ps(acc, 1));       /* a[i] + a[i+8] */
     const __m128 u = _mm_add_ps(_mm256_castps256_ps128(t), _mm256_extractf128_ps(t, 1));                /* t[i] + t[i+4] */
     const __m128 s = _mm_add_ps(u, _mm_movehl_ps(u, u));                                                /* (u0+u2, u1+u3) */
@@ -234,13 +279,19 @@ void ora512_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t
 {
     if (P->blending == ORA_BLEND_RANDOMNESS || W < 2 * LM + 1 || H < 2 * LM + 1) { ora_pass(lr, W, H, P, out, NULL, NULL); return; }
     init_tables();
+    init_perm();
     float wg[PATCH][PATCH];
     ora_gaussian_weights(P->bits, wg);
     const size_t stride = (size_t)W, n = stride * H, slack = 64;
-    float *L = (float *)aligned_alloc(64, ((n + slack) * sizeof(float) + 63) & ~(size_t)63);
-    float *HR = (float *)aligned_alloc(64, ((n + slack) * sizeof(float) + 63) & ~(size_t)63);
-    float *GX = (float *)aligned_alloc(64, ((n + slack) * sizeof(float) + 63) & ~(size_t)63);
-    float *GY = (float *)aligned_alloc(64, ((n + slack) * sizeof(float) + 63) & ~(size_t)63);
+    /* work planes kept between calls (a fresh 4K plane costs more in page faults than the pass spends on it); calls are
+     * serialised by the callers (tests, bench.py), this is not a re-entrant library */
+    static float *planes[4];
+    static size_t plane_cap;
+    if (plane_cap < n + slack) {
+        for (int i = 0; i < 4; i++) { free(planes[i]); planes[i] = (float *)aligned_alloc(64, ((n + slack) * sizeof(float) + 63) & ~(size_t)63); }
+        plane_cap = n + slack;
+    }
+    float *L = planes[0], *HR = planes[1], *GX = planes[2], *GY = planes[3];
     const int rows = 216 * P->pixel_types;
     float *bank = (float *)aligned_alloc(64, (size_t)rows * 128 * sizeof(float));
     for (int i = 0; i < rows; i++) {
@@ -267,8 +318,6 @@ void ora512_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t
     {
         float *ta = (float *)aligned_alloc(64, 3 * (((size_t)W + 31) & ~(size_t)15) * sizeof(float));
         float *tb = ta + (((size_t)W + 31) & ~(size_t)15), *td = tb + (((size_t)W + 31) & ~(size_t)15);
-        float pb[128] __attribute__((aligned(64)));
-        memset(pb, 0, sizeof pb);
         #pragma omp for schedule(dynamic, 2)
         for (int r = LM; r < H - LM; r++) {
             for (int x = LM; x < W - LM; x += 16) {
@@ -282,12 +331,16 @@ void ora512_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t
                 const int legacy = loopItr == 8;
                 int32_t hb[16] __attribute__((aligned(64)));
                 _mm512_store_si512((__m512i *)hb, hash16(_mm512_loadu_ps(ta + c), _mm512_loadu_ps(tb + c), _mm512_loadu_ps(td + c), P, legacy));
-                for (int pix = 0; pix < loopItr; pix++) {
-                    const int cc = c + pix;
-                    int t = 0;
-                    if (P->pixel_types == 4) t = ((r - PM) % 2) * 2 + ((cc - PM) % 2);
-                    const float v = dot121(L, stride, r, cc, bank + ((size_t)hb[pix] * P->pixel_types + t) * 128, pb);
-                    if (v > lo && v < hi) HR[(size_t)r * stride + cc] = v;
+                for (int g = 0; g < loopItr; g += DOT_GROUP) {       /* loopItr is 16 or 8 */
+                    __m512 R[PATCH];
+                    dot_rows(L, stride, r, c + g, R);
+                    for (int sh = 0; sh < DOT_GROUP; sh++) {
+                        const int pix = g + sh, cc = c + pix;
+                        int t = 0;
+                        if (P->pixel_types == 4) t = ((r - PM) % 2) * 2 + ((cc - PM) % 2);
+                        const float v = dot121(R, sh, bank + ((size_t)hb[pix] * P->pixel_types + t) * 128);
+                        if (v > lo && v < hi) HR[(size_t)r * stride + cc] = v;
+                    }
                 }
                 if (loopItr > 8 && c + 2 * unroll > W - LM) loopItr = 8;
                 c += loopItr;
@@ -323,7 +376,7 @@ void ora512_pass(const uint16_t *lr, int W, int H, const ora_pass_t *P, uint16_t
             o[c] = (uint16_t)iv;
         }
     }
-    free(L); free(HR); free(GX); free(GY); free(bank);
+    free(bank);
 }
 
 /* whole Y-plane job: ora_process_y with ora512_pass */

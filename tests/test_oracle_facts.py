@@ -189,3 +189,22 @@ print(json.dumps(got))
     assert len(got) == 2 * len(CASES)
     for k, v in got.items():
         assert want[k] == v, k
+
+
+def test_resize_fast_path_equals_the_generic_form():
+    """ora_resize_bilinear reduces the ratios and works in 32 bits with a multiply-shift division where that is exact; the generic
+    64-bit form is kept as the definition.  Random geometries, ratios and both tie rules."""
+    import ctypes
+    import oracle_py as O
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    for it in range(200):
+        sw, sh = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        r = float(rng.choice([2.0, 1.5, 1.0, 1.7, 1.25, 1.99, 3.0]))
+        dw, dh = max(1, int(sw * r)), max(1, int(sh * r))
+        src = rng.integers(0, 65536, (sh, sw)).astype(np.uint16)
+        for tie in (0, 1):
+            a = np.zeros((dh, dw), np.uint16); b = np.zeros((dh, dw), np.uint16)
+            L.ora_resize_bilinear(src.ctypes.data_as(ctypes.c_void_p), sw, sh, sw, a.ctypes.data_as(ctypes.c_void_p), dw, dh, dw, tie)
+            L.ora_resize_bilinear_generic(src.ctypes.data_as(ctypes.c_void_p), sw, sh, sw, b.ctypes.data_as(ctypes.c_void_p), dw, dh, dw, tie)
+            assert np.array_equal(a, b), (sw, sh, dw, dh, tie)

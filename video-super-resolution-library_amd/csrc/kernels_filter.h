@@ -255,8 +255,14 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
+#ifdef RAISR_EXP_PERSIST_PRIO
+    __builtin_amdgcn_s_setprio(3);                           // experiment: filter-stage waves first (what oldest-first arbitration gives the non-persistent grid)
+#endif
     if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
     else if (sH[tid] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+#ifdef RAISR_EXP_PERSIST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 template <typename T, int PART = 0>

@@ -176,10 +176,10 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
 // A copy from or to pageable memory is staged by the runtime on the calling thread; a copy on page-locked memory is a DMA the
 // copy engines run next to the kernels.  Hosts like FFmpeg recycle a handful of frame buffers through a pool, so the planes
 // RNLProcess sees are page-locked on first sight and remembered (bounded, least-recently-used region dropped; everything is
-// unlocked in RNLDeinit).  Registration works on whole pages, and the runtime refuses a copy whose host range is only PARTLY
-// inside a registered region -- so regions are kept disjoint and a plane that touches registered pages without lying inside
-// one region gets the union of everything it touches registered as ONE region (after waiting for the frames in flight, whose
-// copies may use the regions being replaced).  A stale region -- the host freed the buffer and the allocator reused the
+// unlocked in RNLDeinit).  The runtime refuses a copy whose host range is only PARTLY inside a registered range -- so the
+// ranges (exact plane extents, not rounded to pages) are kept disjoint, and a plane that overlaps registered ranges without
+// lying inside one (a band of rows registered first, the whole plane later) gets the union registered as ONE range, after
+// waiting for the frames in flight, whose copies may use the ranges being replaced.  A stale region -- the host freed the buffer and the allocator reused the
 // address -- is harmless on this platform: the driver tracks registered user pages with MMU notifiers and re-validates the
 // range (tests/test_gpu_host_api.py::test_registered_planes_survive_free_and_reuse).  RAISR_HIP_PIN=0 turns the cache off.
 void quiesceDevice();
@@ -211,8 +211,9 @@ struct PinCache {
     void pin(const void *p, size_t bytes)
     {
         if (!on() || !p || !bytes) return;
-        const uintptr_t page = 4096;
-        uintptr_t lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+        // the EXACT byte range: the runtime keys a registration by the range it was given (it locks the pages underneath), so a
+        // neighbouring buffer that merely shares the first or last page is not "partly registered"
+        uintptr_t lo = (uintptr_t)p, hi = (uintptr_t)p + bytes;
         std::vector<size_t> hit;
         for (size_t i = 0; i < ents.size(); i++)
             if (ents[i].hi > lo && ents[i].lo < hi) hit.push_back(i);
