@@ -417,3 +417,32 @@ def test_registered_planes_survive_free_and_reuse():
             libc.free(a)
             if b != a:
                 libc.free(b)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 4])
+def test_plugin_path_with_row_chunks_and_strided_planes(chunks, monkeypatch):
+    """RNLHandler_Process with the last pass cut into row ranges (RAISR_HIP_CHUNKS): rows are downloaded while later rows are still
+    being computed -- same bits, Y and chroma, with steps larger than the rows and a frame height that is no multiple of anything."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    monkeypatch.setenv("RAISR_HIP_CHUNKS", str(chunks))
+    w, h = 322, 181
+    ys = [synth.natural_y(w, h, 8, seed=70 + i) for i in range(3)]
+    u = synth.random_y(w // 2, h // 2, 8, seed=5); v = synth.random_y(w // 2, h // 2, 8, seed=6)
+    cw, ch = w // 2, h // 2
+    oy = _strided(np.zeros((2 * h, 2 * w), np.uint8), 24)
+    ou, ov = _strided(np.zeros((2 * ch, 2 * cw), np.uint8), 8), _strided(np.zeros((2 * ch, 2 * cw), np.uint8), 8)
+    for passes, fold in ((1, "filters_2x/filters_highres"), (2, "filters_2x/filters_denoise")):
+        assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+        assert R.RNLHandler_Init(folder(fold), 2.0, 8, R.VideoRange, 20, R.HIP, passes, 1) == 0
+        try:
+            assert R.RNLHandler_SetRes((ys[0], u, v), (oy, ou, ov)) == 0
+            for y in ys:
+                oy[...] = 0
+                assert R.RNLHandler_Process((_strided(y, 10), u, v), (oy, ou, ov)) == 0
+                assert np.array_equal(oy, oracle_y(y, ("x", fold, (2, 1), 8, passes, 1, 2, False)))
+                assert np.array_equal(ou, O.resize(u, 2 * cw, 2 * ch).astype(np.uint8)) and np.array_equal(ov, O.resize(v, 2 * cw, 2 * ch).astype(np.uint8))
+            assert R.RNLHandler_Process((ys[0], u, v), (oy, ou, ov), R.Randomness) == 0           # not chunked: same entry, other blend
+        finally:
+            assert R.RNLHandler_Deinit() == 0

@@ -20,8 +20,11 @@ PIPELINES = {
     "unfused": {"RAISR_HIP_FUSED": "0"},
     "exact": {"RAISR_HIP_CERTIFY": "0"},
     "exact_unfused": {"RAISR_HIP_CERTIFY": "0", "RAISR_HIP_FUSED": "0"},
+    # host-plane entry: last pass in row ranges, finished rows downloaded while the next range is computed
+    "chunks3": {"RAISR_HIP_CHUNKS": "3"},
+    "chunks8": {"RAISR_HIP_CHUNKS": "8"},
 }
-CERTIFIED = ("default", "split_lds", "split_l1")
+CERTIFIED = ("default", "split_lds", "split_l1", "chunks3")
 
 # (id, folder, ratio, bits, passes, mode, asm, full)
 CASES = [
@@ -63,7 +66,7 @@ def _run(R, y, case, check=None, blending=None):
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_every_selectable_pipeline_is_bit_exact(pipeline, case, monkeypatch):
     import raisr_hip as R
-    for k in ("RAISR_HIP_SPLIT", "RAISR_HIP_LDS_FILTER", "RAISR_HIP_FUSED", "RAISR_HIP_CERTIFY", "RAISR_HIP_FAST"):
+    for k in ("RAISR_HIP_SPLIT", "RAISR_HIP_LDS_FILTER", "RAISR_HIP_FUSED", "RAISR_HIP_CERTIFY", "RAISR_HIP_FAST", "RAISR_HIP_CHUNKS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in PIPELINES[pipeline].items():
         monkeypatch.setenv(k, v)

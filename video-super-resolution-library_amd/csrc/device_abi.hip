@@ -197,6 +197,10 @@ struct raisr_hip_ctx {
     bool legacy_pending = false;               // ring context that took the two-stream branch of process_host_async (rows != NULL)
     // bands of one frame on several contexts (raisr_hip_set_after): this context's Y kernels start when the previous band's are
     // done, so that the bands' kernels run one after the other while band k's download overlaps band k+1's kernels
+    // host-plane entry, whole frames: the last pass runs in `chunks` row ranges and every finished range is downloaded on the
+    // second stream while the next one is computed (RAISR_HIP_CHUNKS; 1 = one download after the frame)
+    int chunks = 1;
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     raisr_hip_ctx* after = nullptr;
     hipEvent_t ev_kern = nullptr;
     bool ev_kern_valid = false;
@@ -323,8 +327,14 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
 }
 
 // one RAISR pass on an LR plane already resident in c->d_lr[pass]
-template <typename TOut>
-void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+// Row chunks of the LAST pass for the host-plane entry (RowsDone): the fused certified kernel and the census blend are launched on
+// `nchunks` ranges of tile rows, and after each range `done(first_row, row_count)` runs (it enqueues the download of those
+// output rows), so that the copy engine returns finished rows while the next rows are still being computed.  Blend tile row b
+// (pixel rows [16 b, 16 b + 16)) reads HR rows up to 16 b + 16, i.e. filter tile rows <= b: the same ranges serve both kernels.
+struct NoRowsDone { void operator()(int, int) const {} };
+
+template <typename TOut, typename RowsDone = NoRowsDone>
+void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems, int nchunks = 1, RowsDone done = RowsDone())
 {
     const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
     const int W = c->passW[pass], H = c->passH[pass];
@@ -390,6 +400,25 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
             }
+        } else if (c->fused && c->certify && nchunks > 1 && !P.randomness && (int)gf.y >= 2 * nchunks) {
+            P.write_hash = c->keep_hash_plane;
+            P.cert_stats = c->d_cert_stats;
+            P.cert_check = c->cert_check;
+            const int Ty = (int)gf.y, Tb = (H + 15) / 16;
+            for (int i = 0; i < nchunks; i++) {
+                const int t0 = (int)((long long)Ty * i / nchunks), t1 = (int)((long long)Ty * (i + 1) / nchunks);
+                const int b1 = i == nchunks - 1 ? Tb : t1;
+                P.tile_y0 = t0;
+                timer_begin(c, "k_hashfilter_ac", s, slot);
+                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                timer_end(c, s, slot);
+                timer_begin(c, "k_blend", s, slot);
+                hipLaunchKernelGGL((k_blend<TOut>), dim3((W + 63) / 64, (unsigned)(b1 - t0)), dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
+                timer_end(c, s, slot);
+                const int r0 = 16 * t0, r1 = i == nchunks - 1 ? H : 16 * t1;
+                done(r0, r1 - r0);
+            }
+            return;
         } else if (c->fused && c->certify) {
             P.write_hash = c->keep_hash_plane;
             P.cert_stats = c->d_cert_stats;
@@ -446,12 +475,14 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         timer_begin(c, "k_blend_rand", s, slot);
         hipLaunchKernelGGL((k_blend_rand<TOut, false>), gb, dim3(256), 0, s, (const TOut*)lrp, (const void*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
         timer_end(c, s, slot);
+        done(0, H);
         return;
     }
     dim3 gb((W + 63) / 64, (H + 15) / 16);
     timer_begin(c, "k_blend", s, slot);
     hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
+    done(0, H);
 }
 
 // one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
@@ -609,6 +640,7 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
+    if (const char* e = getenv("RAISR_HIP_CHUNKS")) { const int v = atoi(e); c->chunks = v < 1 ? 1 : (v > 8 ? 8 : v); }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 4) c->n_cus = prop.multiProcessorCount & ~3;
@@ -689,6 +721,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_kern) (void)hipEventDestroy(c->ev_kern);
+    for (hipEvent_t& e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) { c->stream = c->own_stream; c->own_stream = nullptr; }
     if (c->d_gauss) (void)hipFree(c->d_gauss);
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
@@ -957,7 +990,12 @@ int raisr_hip_set_blending(raisr_hip_ctx* c, int blending)
     return RAISR_HIP_OK;
 }
 
-int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream)
+} // extern "C"
+
+// process_y_device with the last pass in `nchunks` row ranges and a callback per finished range (see run_pass)
+template <typename RowsDone>
+static int process_y_device_impl(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream,
+                                 int nchunks, RowsDone done)
 {
     if (!c || !d_in || !d_out) return fail(RAISR_HIP_EINVAL, "null argument");
     if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
@@ -979,7 +1017,7 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
         c->lr0_alias = (g.in_width == c->passW[0] && g.in_height == c->passH[0] && ipe == c->passW[0]) ? d_in : nullptr;
         if (!c->lr0_alias) launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
         if (g.passes == 1) {
-            if (fp16) run_pass16<T>(c, s, 0, d_out, ope); else run_pass<T>(c, s, 0, d_out, ope);
+            if (fp16) { run_pass16<T>(c, s, 0, d_out, ope); done(0, g.out_height); } else run_pass<T>(c, s, 0, d_out, ope, nchunks, done);
             return;
         }
         // pass 1 writes the integer intermediate (Raisr.cpp:927-934).  When both passes run at output size
@@ -990,11 +1028,18 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
             ResizeParams R1 = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
             launch_resize<T, T>(c, s, c->d_mid, c->d_lr[1], R1, "k_resize");
         }
-        if (fp16) run_pass16<T>(c, s, 1, d_out, ope); else run_pass<T>(c, s, 1, d_out, ope);
+        if (fp16) { run_pass16<T>(c, s, 1, d_out, ope); done(0, g.out_height); } else run_pass<T>(c, s, 1, d_out, ope, nchunks, done);
     };
     if (bps == 1) job(uint8_t{}); else job(uint16_t{});
     HIP_TRY(hipGetLastError());
     return RAISR_HIP_OK;
+}
+
+extern "C" {
+
+int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream)
+{
+    return process_y_device_impl(c, d_in, in_pitch, d_out, out_pitch, stream, 1, NoRowsDone());
 }
 
 int raisr_hip_resize_plane_device(raisr_hip_ctx* c, const void* d_src, int sw, int sh, size_t spitch,
@@ -1225,15 +1270,53 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     // runs on a second stream so its PCIe transfers overlap the Y kernels.
     const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
     const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
+    bool y_chunked = false;                    // Y rows already on their way back (stage 0 only: upload and download in one call)
     if (do_up) {
         HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
         if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
             HIP_TRY(copy_plane(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
         if (c->after && c->after->ev_kern_valid) HIP_TRY(hipStreamWaitEvent(s, c->after->ev_kern, 0));
-        int rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
+        int rc;
+        y_chunked = !rows && do_down && c->chunks > 1 && c->blending != RAISR_HIP_BLEND_RANDOMNESS;
+        bool chroma_done = false;
+        if (y_chunked && chroma) {
+            // the second stream carries the Y rows back as they are finished: the (cheap) chroma planes go through it first, their
+            // download uses the link while nothing else does
+            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+            rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
+            if (rc) return rc;
+            if (c_keep > 0) {
+                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+            }
+            chroma_done = true;
+        }
+        if (y_chunked) {
+            // whole frame, synchronous caller: rows leave as they are finished.  The callback runs right after a range's kernels
+            // are enqueued on s: an event marks the point, the second stream waits for it and copies the rows back.
+            int idx = 0;
+            hipError_t cb_err = hipSuccess;
+            auto rows_done = [&](int r0, int n) {
+                if (cb_err != hipSuccess || n <= 0) return;
+                hipEvent_t& ev = c->ev_chunk[idx & 7];
+                idx++;
+                if (!ev) cb_err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (cb_err == hipSuccess) cb_err = hipEventRecord(ev, s);
+                if (cb_err == hipSuccess) cb_err = hipStreamWaitEvent(s2, ev, 0);
+                if (cb_err == hipSuccess)
+                    cb_err = copy_plane((char*)out_y + (size_t)r0 * out_y_pitch, out_y_pitch, d + off_oy + (size_t)r0 * orow, orow, orow, (size_t)n, hipMemcpyDeviceToHost, s2);
+            };
+            rc = process_y_device_impl(c, d, irow, d + off_oy, orow, s, c->chunks, rows_done);
+            if (!rc && cb_err != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "chunked download", cb_err);
+        } else {
+            rc = raisr_hip_process_y_device(c, d, irow, d + off_oy, orow, s);
+        }
         if (rc) return rc;
         if (c->ev_kern) { HIP_TRY(hipEventRecord(c->ev_kern, s)); c->ev_kern_valid = true; }
-        if (chroma) {
+        if (chroma && !chroma_done) {
             HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
@@ -1246,7 +1329,7 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         // Packed output frame: when the caller's three output planes sit in host memory exactly as the staging planes sit in
         // device memory (raisr_hip_packed_frame_layout), the whole frame goes back as ONE copy -- fewer, larger PCIe
         // transfers (the download is what bounds a streamed 4K job: 12.4 MB per frame).
-        const bool packed = chroma && !rows && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
+        const bool packed = chroma && !rows && !y_chunked && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
                             (const char*)out_u == (const char*)out_y + (off_ou - off_oy) && (const char*)out_v == (const char*)out_y + (off_ov - off_oy);
         if (packed) {
             if (!c->ev_chroma) HIP_TRY(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
@@ -1254,11 +1337,11 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
             HIP_TRY(hipStreamWaitEvent(s, c->ev_chroma, 0));
             HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, s));
         } else {
-            if (chroma && c_keep > 0) {
+            if (chroma && c_keep > 0 && !y_chunked) {
                 HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
                 HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
             }
-            if (y_keep > 0) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
+            if (y_keep > 0 && !y_chunked) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
         }
     }
     return RAISR_HIP_OK;

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
     xcd_tile(bx, by);
+    by += P.tile_y0;
     const int c0 = bx * TW, r0 = by * TH;
     {   // wave w sweeps columns [0,64) of tile rows w, w+4, ...; the two right-hand halo columns go to the first 36 threads.
         // All LR and HR loads of a thread are in flight before the first LDS write.

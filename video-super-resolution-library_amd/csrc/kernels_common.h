@@ -36,6 +36,8 @@ struct PassParams {
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
+    int tile_y0;                 // first tile row of this launch (k_hashfilter_ac / k_blend launched on a range of tile rows: the host
+                                 // path pipelines the download of finished rows with the kernels of the next rows)
 };
 
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ 
 
     int bx, by;
     xcd_tile(bx, by);
+    by += P.tile_y0;
     hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 
