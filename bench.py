@@ -620,6 +620,7 @@ def main():
         res = stream_leg(R, wl, gpu, len(mine), blobs=blobs)
         dt = len(mine) / res["fps"]
         fence()
+        dt_ranks = sharding.gather_over_ranks(dt, dev, dist if use_dist else None)
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
         frames_total = len(mine) * world
         lanes = []
@@ -631,6 +632,7 @@ def main():
         host_frames = wl.frames(args.frame_kind, mine)
         dt, kern, lanes, d_in, d_out = device_loop(R, torch, wl, gpu, blobs, args.lanes, host_frames, nf, args.steps, args.warmup,
                                                    fence, timing)
+        dt_ranks = sharding.gather_over_ranks(dt, dev, dist if use_dist else None)
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
         frames_total = nf * args.steps * world
         if timing and rank == 0:
@@ -651,8 +653,12 @@ def main():
             multi_stream = {"value": None, "error": f"{type(e).__name__}: {e}"}
             sharding.max_over_ranks(0.0, dev, dist if use_dist else None)
 
+    numa_ranks = sharding.gather_strings(numa or "unbound (single rank)", dist if use_dist else None) if world > 1 else None
     if rank == 0:
-        mp_s = wl.out_w * wl.out_h * frames_total / dt / 1e6
+        # whole-job rate = all ranks' frames over the SLOWEST rank's time (sharding.job_rate; tests/test_distributed_gloo.py)
+        fps_job, fps_ranks = sharding.job_rate([frames_total / world] * world, dt_ranks)
+        assert abs(fps_job - frames_total / dt) <= 1e-6 * fps_job
+        mp_s = wl.out_w * wl.out_h * fps_job / 1e6
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
         roofline = roofline_of(wl, kern, iso, args.lanes)
         fast_level = lanes[0].fast() if lanes and hasattr(lanes[0], "fast") else int(os.environ.get("RAISR_HIP_FAST", "0") or 0)
@@ -725,7 +731,9 @@ def main():
                        "frame_kind": args.frame_kind, "mode": "exact" if not fast_level else f"fast-{fast_level} (NOT bit-exact: RAISR_HIP_FAST is set)",
                        "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
                        "timed_region_s": round(dt, 3),
-                       "parallelism": f"frame-shard x{world}"} | ({"numa_rank0": numa} if numa else {}),
+                       "parallelism": f"frame-shard x{world}"} |
+                      ({"numa_ranks": numa_ranks, "fps_per_rank": {"min": round(min(fps_ranks), 2), "max": round(max(fps_ranks), 2),
+                                                                   "all": [round(f, 2) for f in fps_ranks]}} if world > 1 else {}),
             "kernels_avg_ms": kernels_ms,
             "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()},
             "roofline": roofline,

@@ -122,3 +122,25 @@ int main() {
     assert out.returncode == 0, out.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "cpp-client-ok" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-500:])
+
+
+def test_static_flavour_links_from_plain_c(tmp_path):
+    """libraisr.a (the reference ships a static library, Library/CMakeLists.txt:24,44-45): a C99 program links against it with
+    -lstdc++ -lamdhip64 and runs the host-only entry points (no device needed for these)."""
+    import shutil
+    import subprocess
+    pkg = os.path.join(ROOT, "video-super-resolution-library_amd")
+    rocm_lib = "/opt/rocm/lib"
+    if not (shutil.which("ar") and os.path.exists(os.path.join(rocm_lib, "libamdhip64.so"))):
+        import pytest
+        pytest.skip("needs ar and the HIP runtime to link against")
+    subprocess.check_call(["make", "-s", "-C", pkg, "libraisr.a"])
+    src = tmp_path / "main.c"
+    src.write_text('#include <stdio.h>\n#include "raisr/RaisrHandler.h"\n#include "raisr_hip.h"\n'
+                   'int main(void) { if (RNLHandler_Collect() != RNLErrorBadParameter) return 2;\n'
+                   '  printf("%s %d\\n", raisr_hip_version(), (int)RNLHandler_Deinit()); return 0; }\n')
+    exe = tmp_path / "main"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           os.path.join(pkg, "libraisr.a"), "-L", rocm_lib, "-lamdhip64", "-lstdc++", "-ldl", "-lpthread", "-lm", "-o", str(exe)])
+    out = subprocess.run([str(exe)], env=dict(os.environ, LD_LIBRARY_PATH=rocm_lib), capture_output=True, text=True)
+    assert out.returncode == 0 and "raisr-hip" in out.stdout and out.stdout.strip().endswith(" 0"), (out.stdout, out.stderr)

@@ -31,6 +31,9 @@ def _worker(rank, world, port, q):
     t = sharding.broadcast_model_blob(blob, nbytes, torch.device("cpu"), dist)
     mine = sharding.frames_for_rank(11, rank, world)
     slow = sharding.max_over_ranks(1.0 + rank, torch.device("cpu"), dist)
+    all_t = sharding.gather_over_ranks(1.0 + rank, torch.device("cpu"), dist)
+    names = sharding.gather_strings(f"node {rank}", dist)
+    assert all_t == [1.0, 2.0] and names == ["node 0", "node 1"]
     import hashlib
     q.put((rank, hashlib.sha256(t.numpy().tobytes()).hexdigest(), mine, slow))
     dist.barrier()
@@ -60,3 +63,14 @@ def test_blob_broadcast_and_frame_sharding_world2():
     import raisr_hip as R
     bank, qstr, qcoh, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, 1)
     assert hashlib.sha256(R.pack_model_blob(bank, qstr, qcoh, qa).tobytes()).hexdigest() == h0
+
+
+def test_job_rate_divides_by_the_slowest_rank():
+    """bench.py's N-rank `value`: every rank's frames over the MAX of the per-rank times, never a sum of per-rank rates."""
+    sys.path[:0] = [os.path.join(ROOT, "video-super-resolution-library_amd")]
+    import sharding
+    rate, per_rank = sharding.job_rate([100, 100, 100, 100], [1.0, 1.0, 2.0, 1.0])
+    assert rate == 400 / 2.0 and per_rank == [100.0, 100.0, 50.0, 100.0]
+    assert rate < sum(per_rank)                                   # a straggler costs the whole job
+    rate1, _ = sharding.job_rate([768], [0.5])
+    assert rate1 == 1536.0

@@ -202,51 +202,67 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
     }
     __syncthreads();
 
-    hf2 curA[2], curB[2], curD[2], holdA[2], holdB[2], holdD[2], t1A[2], t1B[2], t1D[2];
     const hf2 z2 = {(hf)0.f, (hf)0.f};
+    // The 11 patch columns in the reference's fold order, as four groups {0,8,4} {2,10,6} {1,9,5} {7,3} = Ga, Gd, Gb, Gc of
+    // sumitup2lane: the fold bookkeeping runs once per group instead of once per column (a third of the rolled loop's
+    // instructions were scalar selects), and a group's running sum starts from +0 (0 + S == S bit for bit: a column sum is
+    // never -0 -- its fma chain starts from +0).  The next column's weights are fetched while the current column computes.
+    hf2 hold_[3][2], t1_[3][2], cur_[3][2];
 #pragma unroll
-    for (int p = 0; p < 2; p++) curA[p] = curB[p] = curD[p] = holdA[p] = holdB[p] = holdD[p] = t1A[p] = t1B[p] = t1D[p] = z2;
-    // the column's 11 weights sit in SGPRs; the NEXT column's are fetched (scalar loads from the kernel arguments) while this
-    // column's 110 packed operations run, instead of at the top of the iteration with nothing to hide their latency
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) hold_[q][p] = t1_[q][p] = cur_[q][p] = z2;
     uint32_t wk[11], wn[11];
 #pragma unroll
     for (int i = 0; i < 11; i++) wk[i] = gw.wT[c_col_order[0]][i];
+    int kk = 0;
 #pragma unroll 1
-    for (int kk = 0; kk < 11; kk++) {
-        const int k = c_col_order[kk];
-        const int kn = c_col_order[kk < 10 ? kk + 1 : 10];
+    for (int grp = 0; grp < 4; grp++) {
 #pragma unroll
-        for (int i = 0; i < 11; i++) wn[i] = gw.wT[kn][i];
-        uint2 g[13];
+        for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int t = 0; t < 13; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
-        hf2 A[2], B[2], D[2];
+            for (int p = 0; p < 2; p++) cur_[q][p] = z2;
+        const int len = grp == 3 ? 2 : 3;
+#pragma unroll 1
+        for (int j = 0; j < len; j++, kk++) {
+            const int k = c_col_order[kk];
+            const int kn = c_col_order[kk < 10 ? kk + 1 : 10];
 #pragma unroll
-        for (int p = 0; p < 2; p++) A[p] = B[p] = D[p] = z2;
+            for (int i = 0; i < 11; i++) wn[i] = gw.wT[kn][i];
+            uint2 g[13];
 #pragma unroll
-        for (int i = 0; i < 11; i++) {
-            const hf2 w2 = __builtin_bit_cast(hf2, wk[i]);
+            for (int t = 0; t < 13; t++) g[t] = sG[(w * R + t) * GW_ + lane + k];
+            hf2 A[2], B[2], D[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) A[p] = B[p] = D[p] = z2;
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                const hf2 w2 = __builtin_bit_cast(hf2, wk[i]);
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const hf2 X = __builtin_bit_cast(hf2, g[i + 2 * p].x), Y = __builtin_bit_cast(hf2, g[i + 2 * p].y);
+                    const hf2 PX = X * w2;
+                    A[p] = __builtin_elementwise_fma(PX, X, A[p]);
+                    B[p] = __builtin_elementwise_fma(PX, Y, B[p]);
+                    const hf2 PY = Y * w2;
+                    D[p] = __builtin_elementwise_fma(PY, Y, D[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) { cur_[0][p] = cur_[0][p] + A[p]; cur_[1][p] = cur_[1][p] + B[p]; cur_[2][p] = cur_[2][p] + D[p]; }
+#pragma unroll
+            for (int i = 0; i < 11; i++) wk[i] = wn[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const hf2 X = __builtin_bit_cast(hf2, g[i + 2 * p].x), Y = __builtin_bit_cast(hf2, g[i + 2 * p].y);
-                const hf2 PX = X * w2;
-                A[p] = __builtin_elementwise_fma(PX, X, A[p]);
-                B[p] = __builtin_elementwise_fma(PX, Y, B[p]);
-                const hf2 PY = Y * w2;
-                D[p] = __builtin_elementwise_fma(PY, Y, D[p]);
+                if (grp == 1) t1_[q][p] = hold_[q][p] + cur_[q][p];          // Ga + Gd
+                if (grp == 0 || grp == 2) hold_[q][p] = cur_[q][p];          // Ga, later Gb
             }
-        }
-        const bool start = (kk == 0) | (kk == 3) | (kk == 6) | (kk == 9);
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            if (start) { curA[p] = A[p]; curB[p] = B[p]; curD[p] = D[p]; }
-            else { curA[p] = curA[p] + A[p]; curB[p] = curB[p] + B[p]; curD[p] = curD[p] + D[p]; }
-            if (kk == 2 || kk == 8) { holdA[p] = curA[p]; holdB[p] = curB[p]; holdD[p] = curD[p]; }
-            if (kk == 5) { t1A[p] = holdA[p] + curA[p]; t1B[p] = holdB[p] + curB[p]; t1D[p] = holdD[p] + curD[p]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 11; i++) wk[i] = wn[i];
     }
+    hf2 *curA = cur_[0], *curB = cur_[1], *curD = cur_[2], *holdA = hold_[0], *holdB = hold_[1], *holdD = hold_[2];
+    hf2 *t1A = t1_[0], *t1B = t1_[1], *t1D = t1_[2];
 
     const int c = c0 + lane;
     const HashQ16 HQ = {Q.qangle, Q.qs0, Q.qs1, Q.qc0, Q.qc1};

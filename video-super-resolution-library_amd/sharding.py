@@ -47,3 +47,31 @@ def max_over_ranks(value, device, dist=None):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device, dist=None):
+    """Every rank's python float, in rank order, on every rank (per-rank timings of the scaling record)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def gather_strings(text, dist=None):
+    """Every rank's short string (e.g. its NUMA binding) in rank order; [text] without a process group."""
+    if dist is None or not dist.is_initialized():
+        return [text]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, text)
+    return out
+
+
+def job_rate(units_per_rank, seconds_per_rank):
+    """Whole-job rate of a sharded run: ALL ranks' units over the time of the SLOWEST rank (the timing contract of bench.py:
+    barrier, timed region, barrier, MAX over ranks).  Also returns the per-rank rates for the record."""
+    slowest = max(seconds_per_rank)
+    per_rank = [u / s for u, s in zip(units_per_rank, seconds_per_rank)]
+    return sum(units_per_rank) / slowest, per_rank
