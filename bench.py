@@ -161,6 +161,11 @@ def cpu_baseline(wl, sample_frames):
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("RAISR_ORACLE_ISA", "auto")
+    try:    # the OpenMP runtime is already initialised when an earlier leg loaded the oracle: the environment variable comes too
+        import ctypes                                   # late then (it would run one thread per visible CPU, far above the quota)
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
 
     def timed(w, n_frames):
         run, how = oracle_runner(w, intrinsics=True)

@@ -58,8 +58,13 @@ typedef struct VideoDataType {
     unsigned int   width;      /* samples per row                                                */
     unsigned int   height;     /* rows                                                           */
     unsigned int   step;
-    unsigned int   bitShift;   /* unused by this backend (as on the reference's CPU path)        */
+    unsigned int   bitShift;   /* low bits: unused by this backend (as on the reference's CPU path); top bit: RAISR_HIP_INTERLEAVED2 */
 } VideoDataType;
+
+/* Extension for device frames (asm = HIPExternal) whose chroma is ONE plane of interleaved (U, V) pairs (NV12 / P010, what
+ * hardware decoders produce): set this bit in the bitShift of BOTH chroma descriptors, point them at the plane's first U and
+ * first V sample (one sample apart), give `width` in samples of one channel and `step` as the plane's pitch in bytes. */
+#define RAISR_HIP_INTERLEAVED2 0x80000000u
 
 /* ---- filter geometry: 11x11 patch, 121 taps --------------------------------------------------- */
 #define defaultPatchSize (11)

@@ -109,11 +109,20 @@ int raisr_hip_resize_plane_device(raisr_hip_ctx *ctx, const void *d_src, int sw,
                                   void *d_dst, int dw, int dh, size_t dpitch, int bits, void *stream);
 /* Whole device-resident frame: RAISR on Y plus the cheap upscale of both chroma planes (RNLProcess's work,
  * Raisr.cpp:1369-1389) without leaving HBM -- the zero-copy analogue of ffmpeg/vf_raisr_opencl.c. */
+/* ... with element steps (2 = one channel of an interleaved two-channel plane: NV12 / P010 chroma) */
+int raisr_hip_resize_plane_device_ex(raisr_hip_ctx *ctx, const void *d_src, int sw, int sh, size_t spitch, int sstep,
+                                     void *d_dst, int dw, int dh, size_t dpitch, int dstep, int bits, void *stream);
 int raisr_hip_process_frame_device(raisr_hip_ctx *ctx,
                                    const void *d_in_y, size_t in_y_pitch, void *d_out_y, size_t out_y_pitch,
                                    const void *d_in_u, const void *d_in_v, size_t in_c_pitch,
                                    void *d_out_u, void *d_out_v, size_t out_c_pitch,
                                    int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h, void *stream);
+/* chroma_step = 2: U and V are the two channels of ONE interleaved plane on both sides (d_*_v = d_*_u + one sample) */
+int raisr_hip_process_frame_device_ex(raisr_hip_ctx *ctx,
+                                      const void *d_in_y, size_t in_y_pitch, void *d_out_y, size_t out_y_pitch,
+                                      const void *d_in_u, const void *d_in_v, size_t in_c_pitch,
+                                      void *d_out_u, void *d_out_v, size_t out_c_pitch,
+                                      int chroma_in_w, int chroma_in_h, int chroma_out_w, int chroma_out_h, int chroma_step, void *stream);
 /* Host planes in, host planes out (what RNLProcess hands over): stages through pinned memory,
  * runs Y + both chroma planes, synchronous.  Chroma pointers may be NULL to skip chroma. */
 int raisr_hip_process_host(raisr_hip_ctx *ctx,

@@ -7,7 +7,7 @@ import raisr_hip as R, synth
 
 w, h = 1920, 1080
 fold = os.path.join(ROOT, "filters_2x", "filters_highres")
-n = 400
+n = int(os.environ.get("N", "400"))
 pinned = int(os.environ.get("PIN", "0"))
 ys = [synth.natural_y(w, h, 8, seed=i) for i in range(4)]
 u = synth.chroma(w // 2, h // 2, 8); v = u.copy()

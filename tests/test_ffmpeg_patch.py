@@ -41,3 +41,22 @@ def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_pat
                           "-I", os.path.join(ROOT, "tests", "ffmpeg_stub"), "-I", os.path.join(ROOT, "include"),
                           str(work / "vf_raisr.c")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_hardware_frames_filter_compiles_against_our_headers():
+    """ffmpeg/vf_raisr_hipframes.c (the counterpart of the reference's vf_raisr_opencl.c: VAAPI surfaces -> DRM PRIME dma-bufs ->
+    HIP device pointers -> ASMType HIPExternal): `gcc -fsyntax-only` against the library's headers, the real HIP runtime API header
+    and the declaration-only libavfilter / hwcontext subset; the calls it makes exist with these signatures."""
+    hip_inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(hip_inc, "hip", "hip_runtime_api.h")):
+        pytest.skip("needs the HIP runtime headers")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    src = os.path.join(ROOT, "ffmpeg", "vf_raisr_hipframes.c")
+    out = subprocess.run([cc, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wno-unused-variable", "-D__HIP_PLATFORM_AMD__",
+                          "-I", os.path.join(ROOT, "tests", "ffmpeg_stub"), "-I", os.path.join(ROOT, "include"), "-I", hip_inc, src],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    text = open(src).read()
+    for needle in ("hipImportExternalMemory", "hipExternalMemoryGetMappedBuffer", "HIPExternal", "RAISR_HIP_INTERLEAVED2",
+                   "RNLHandler_SetOpenCLContext(ctx->stream, NULL, 0, ctx->device)", "DRM_FORMAT_MOD_LINEAR_", "FF_FILTER_FLAG_HWFRAME_AWARE"):
+        assert needle in text, needle

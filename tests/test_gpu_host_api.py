@@ -446,3 +446,61 @@ def test_plugin_path_with_row_chunks_and_strided_planes(chunks, monkeypatch):
             assert R.RNLHandler_Process((ys[0], u, v), (oy, ou, ov), R.Randomness) == 0           # not chunked: same entry, other blend
         finally:
             assert R.RNLHandler_Deinit() == 0
+
+
+@pytest.mark.parametrize("bits,ratio", [(8, (2, 1)), (10, (2, 1)), (8, (3, 2))])
+def test_hipexternal_nv12_style_interleaved_chroma(bits, ratio):
+    """Device frames as hardware decoders produce them (NV12 / P010: one chroma plane of interleaved (U, V) pairs) -- what
+    ffmpeg/vf_raisr_hipframes.c hands over: both chroma descriptors carry RAISR_HIP_INTERLEAVED2 and point one sample apart into
+    the same plane.  Y against the oracle, each chroma channel against the oracle's cheap upscale; padding bytes untouched."""
+    import ctypes
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    import torch
+    rn, rd = ratio
+    w, h = 176, 100
+    ow, oh = w * rn // rd, h * rn // rd
+    cw, ch, ocw, och = w // 2, h // 2, ow // 2, oh // 2
+    fold = "filters_2x/filters_highres" if rn == 2 else "filters_1.5x/filters_highres"
+    tdt = torch.uint8 if bits == 8 else torch.uint16
+    ndt = np.uint8 if bits == 8 else np.uint16
+    bps = 1 if bits == 8 else 2
+    FLAG = 0x80000000
+    y = synth.natural_y(w, h, bits, seed=41)
+    u = synth.random_y(cw, ch, bits, seed=42).astype(ndt)
+    v = synth.random_y(cw, ch, bits, seed=43).astype(ndt)
+    uv = np.zeros((ch, 2 * cw + 12), ndt)
+    uv[:, 0:2 * cw:2] = u; uv[:, 1:2 * cw:2] = v
+
+    def to_dev(a):
+        return torch.from_numpy(a.view(np.int16) if bits != 8 else a).cuda().view(tdt)
+    dy = to_dev(np.ascontiguousarray(y)); duv = to_dev(uv)
+    oy = torch.zeros((oh, ow + 8), dtype=tdt, device="cuda")
+    ouv = torch.full((och, 2 * ocw + 20), 7, dtype=tdt, device="cuda")
+
+    def vdt(ptr, width, height, step, shift=0):
+        d = R.VideoDataType()
+        d.pData = ptr; d.width = width; d.height = height; d.step = step; d.bitShift = shift
+        return d
+    ds = [vdt(dy.data_ptr(), w, h, dy.stride(0) * bps),
+          vdt(duv.data_ptr(), cw, ch, duv.stride(0) * bps, FLAG), vdt(duv.data_ptr() + bps, cw, ch, duv.stride(0) * bps, FLAG),
+          vdt(oy.data_ptr(), ow, oh, oy.stride(0) * bps),
+          vdt(ouv.data_ptr(), ocw, och, ouv.stride(0) * bps, FLAG), vdt(ouv.data_ptr() + bps, ocw, och, ouv.stride(0) * bps, FLAG)]
+    refs = [ctypes.byref(x) for x in ds]
+    assert R.RNLHandler_SetOpenCLContext(0, 0, None) == 0
+    assert R.RNLHandler_Init(folder(fold), rn / rd, bits, R.VideoRange, 20, R.HIPExternal, 1, 1) == 0
+    try:
+        torch.cuda.synchronize()
+        assert R.lib().RNLHandler_SetRes(*refs) == 0
+        assert R.lib().RNLHandler_Process(*refs, R.CountOfBitsChanged) == 0
+        ds[2].bitShift = 0                                   # the flag on one side only: refused
+        assert R.lib().RNLHandler_Process(*refs, R.CountOfBitsChanged) == R.RNLErrorBadParameter
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(oy[:, :ow].cpu().numpy().view(ndt), oracle_y(y, ("x", fold, ratio, bits, 1, 1, 2, False)))
+    got = ouv.cpu().numpy().view(ndt)
+    assert np.array_equal(got[:, 0:2 * ocw:2], O.resize(u, ocw, och).astype(ndt))
+    assert np.array_equal(got[:, 1:2 * ocw:2], O.resize(v, ocw, och).astype(ndt))
+    assert np.all(got[:, 2 * ocw:] == 7)

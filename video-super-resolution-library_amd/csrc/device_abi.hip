@@ -267,6 +267,7 @@ ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch,
 {
     ResizeParams R{};
     R.sw = sw; R.sh = sh; R.dw = dw; R.dh = dh; R.spitch = spitch; R.dpitch = dpitch;
+    R.sstep = R.dstep = 1;
     const int gx = gcd_int(sw, dw), gy = gcd_int(sh, dh);
     R.Sx = sw / gx; R.Dx = dw / gx; R.Sy = sh / gy; R.Dy = dh / gy;
     R.tie_even = tie == RAISR_HIP_TIE_HALF_EVEN;
@@ -285,7 +286,10 @@ void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, 
 {
     int slot;
     timer_begin(c, name, s, slot);
-    if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
+    if (R.sstep != 1 || R.dstep != 1) {                      // one channel of an interleaved plane: the generic kernel addresses by element step
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
+    } else if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
         dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
         hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (2 * R.dw == 3 * R.sw && 2 * R.dh == 3 * R.sh) {
@@ -447,6 +451,11 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                     hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
                                        c->n_cus, 0, ctr);
                 } else
+#endif
+#ifdef RAISR_EXP_TILE8
+                if (getenv("RAISR_HIP_TILE8"))
+                    hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 2>), dim3(gf.x, (unsigned)((H - 2 * kMargin + 7) / 8)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                else
 #endif
                 hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
@@ -1045,11 +1054,21 @@ int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pit
 int raisr_hip_resize_plane_device(raisr_hip_ctx* c, const void* d_src, int sw, int sh, size_t spitch,
                                   void* d_dst, int dw, int dh, size_t dpitch, int bits, void* stream)
 {
+    return raisr_hip_resize_plane_device_ex(c, d_src, sw, sh, spitch, 1, d_dst, dw, dh, dpitch, 1, bits, stream);
+}
+
+// ... with element steps: sstep / dstep = 2 addresses one channel of an interleaved two-channel plane (NV12 / P010 chroma); the
+// pointers then point at the channel's first sample and the widths count samples of that channel
+int raisr_hip_resize_plane_device_ex(raisr_hip_ctx* c, const void* d_src, int sw, int sh, size_t spitch, int sstep,
+                                     void* d_dst, int dw, int dh, size_t dpitch, int dstep, int bits, void* stream)
+{
     if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (sstep < 1 || sstep > 4 || dstep < 1 || dstep > 4) return fail(RAISR_HIP_EINVAL, "element step out of range");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int bps = bits == 8 ? 1 : 2;
     ResizeParams R = make_resize(sw, sh, (int)(spitch / bps), dw, dh, (int)(dpitch / bps), c->configured ? c->cfg.tie_rule : 0);
+    R.sstep = sstep; R.dstep = dstep;
     if (bps == 1) launch_resize<uint8_t, uint8_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
     else launch_resize<uint16_t, uint16_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
     HIP_TRY(hipGetLastError());
@@ -1064,13 +1083,24 @@ int raisr_hip_process_frame_device(raisr_hip_ctx* c,
                                    void* d_out_u, void* d_out_v, size_t out_c_pitch,
                                    int cin_w, int cin_h, int cout_w, int cout_h, void* stream)
 {
+    return raisr_hip_process_frame_device_ex(c, d_in_y, in_y_pitch, d_out_y, out_y_pitch, d_in_u, d_in_v, in_c_pitch, d_out_u, d_out_v, out_c_pitch,
+                                             cin_w, cin_h, cout_w, cout_h, 1, stream);
+}
+
+// chroma_step = 2: U and V are the two channels of ONE interleaved plane (NV12 / P010), on the input and on the output side
+int raisr_hip_process_frame_device_ex(raisr_hip_ctx* c,
+                                      const void* d_in_y, size_t in_y_pitch, void* d_out_y, size_t out_y_pitch,
+                                      const void* d_in_u, const void* d_in_v, size_t in_c_pitch,
+                                      void* d_out_u, void* d_out_v, size_t out_c_pitch,
+                                      int cin_w, int cin_h, int cout_w, int cout_h, int chroma_step, void* stream)
+{
     if (!c || !d_in_u || !d_in_v || !d_out_u || !d_out_v) return fail(RAISR_HIP_EINVAL, "null plane");
     if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
     int rc = raisr_hip_process_y_device(c, d_in_y, in_y_pitch, d_out_y, out_y_pitch, stream);
     if (rc) return rc;
-    rc = raisr_hip_resize_plane_device(c, d_in_u, cin_w, cin_h, in_c_pitch, d_out_u, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+    rc = raisr_hip_resize_plane_device_ex(c, d_in_u, cin_w, cin_h, in_c_pitch, chroma_step, d_out_u, cout_w, cout_h, out_c_pitch, chroma_step, c->cfg.bits, stream);
     if (rc) return rc;
-    return raisr_hip_resize_plane_device(c, d_in_v, cin_w, cin_h, in_c_pitch, d_out_v, cout_w, cout_h, out_c_pitch, c->cfg.bits, stream);
+    return raisr_hip_resize_plane_device_ex(c, d_in_v, cin_w, cin_h, in_c_pitch, chroma_step, d_out_v, cout_w, cout_h, out_c_pitch, chroma_step, c->cfg.bits, stream);
 }
 
 int raisr_hip_synchronize(raisr_hip_ctx* c)

@@ -33,7 +33,7 @@ __device__ __forceinline__ float tree16(float acc)
 
 // filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
-template <int LW>
+template <int LW, int RPW = 4>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
                                              int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x)
 {
@@ -56,8 +56,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1
-    for (int row = 0; row < 4; row++) {
-        const int prow = 4 * w + row;
+    for (int row = 0; row < RPW; row++) {
+        const int prow = RPW * w + row;
         const int r = r0 + prow;
         const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kTapsPad * 4) : 0u;
         const unsigned row_lane_off = trow_off + lane_off;
@@ -203,12 +203,13 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
 // one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
-template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT>
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4>
 __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
                                                    uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
-                                                   float* sL, GT* sG, float4* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x)
+                                                   float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x)
 {
-    constexpr int TW = 64, TH = 16;
+    constexpr int TW = 64, TH = 4 * RPW;
+    static_assert(LH == TH + 12 && GH == TH + 10, "window and gradient tile follow the tile height");
     const int lane = tid & 63, w = tid >> 6;
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
@@ -235,7 +236,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         }
     }
     __syncthreads();
-    if (PART != 2) hash_phase_ac<LW, GT>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
+    if (PART != 2) hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
     else {
         // P.cert_check doubles as the bucket pattern of this profiling aid: 0 = every row of the bank, 1 = one row, 2 = sixteen rows
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
@@ -244,9 +245,9 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     if (P.write_hash) {
         const int c = c0 + lane;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = r0 + 4 * w + j;
-            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(4 * w + j) * TW + lane];
+        for (int j = 0; j < RPW; j++) {
+            const int r = r0 + RPW * w + j;
+            if (r < P.H - kMargin && c < P.c_final) hash_out[(unsigned)r * (unsigned)P.hash_pitch + (unsigned)c] = sH[(RPW * w + j) * TW + lane];
         }
     }
     if (P.cert_stats && tid == 0) {
@@ -258,23 +259,26 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
 #ifdef RAISR_EXP_PERSIST_PRIO
     __builtin_amdgcn_s_setprio(3);                           // experiment: filter-stage waves first (what oldest-first arbitration gives the non-persistent grid)
 #endif
-    if (PART != 1) filter_phase<LW>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
-    else if (sH[tid] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+    if (PART != 1) filter_phase<LW, RPW>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
+    else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
 #ifdef RAISR_EXP_PERSIST_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
-template <typename T, int PART = 0>
-__global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
-                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
+#ifndef RAISR_EXP_TILE8_WGS
+#define RAISR_EXP_TILE8_WGS 6
+#endif
+template <typename T, int PART = 0, int RPW = 4>
+__global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+                                                                         uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
-    constexpr int TW = 64, TH = 16;
+    constexpr int TW = 64, TH = 4 * RPW;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
     __shared__ float sL[LH * LW];
     using GT = typename GradOf<T>::type;
     __shared__ GT sG[GH * GW_];
-    __shared__ float4 sV[3 * 4 * GW_];
+    __shared__ typename FVec<RPW>::type sV[3 * 4 * GW_];
     uint2* sTab = reinterpret_cast<uint2*>(sV);   // the exact path's table takes sV's place once the H pass is done (hash_phase_ac)
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter_ac(const T* __restrict__ 
     int bx, by;
     xcd_tile(bx, by);
     by += P.tile_y0;
-    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 
 #ifdef RAISR_EXP_PERSIST
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(c
     __shared__ float sL[LH * LW];
     using GT = typename GradOf<T>::type;
     __shared__ GT sG[GH * GW_];
-    __shared__ float4 sV[3 * 4 * GW_];
+    __shared__ typename FVec<4>::type sV[3 * 4 * GW_];
     uint2* sTab = reinterpret_cast<uint2*>(sV);
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];

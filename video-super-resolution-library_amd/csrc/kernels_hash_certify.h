@@ -154,22 +154,29 @@ __device__ __forceinline__ void exact_tensor16(const GT* sG, const float (&wl)[1
     d = fold11(AD.y, lane3);
 }
 
-// Approximate structure tensor of the lane's 4 pixels (rows [4w, 4w+4) of the tile, column = lane): separable 11 + 11 taps
-// on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [4 rg, 4 rg + 4),
-// results as float4 per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
-template <typename GT>
-__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4], unsigned tid = threadIdx.x)
+// Approximate structure tensor of the lane's RPW pixels (rows [RPW w, RPW w + RPW) of the tile, column = lane): separable 11 + 11
+// taps on the gradient products.  V pass: lane-task (x, rg) = column x of the gradient tile, output rows [RPW rg, RPW rg + RPW),
+// results as one RPW-vector per (channel, row group, column) in sV; workgroup barrier; H pass: lane = column, wave = row group.
+// (RPW = 4: the 64 x 16 tile; RPW = 2: the 64 x 8 tile.)
+template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
+
+template <int RPW, typename GT>
+__device__ __forceinline__ void tensor_acN(const SepW& S, const GT* sG, typename FVec<RPW>::type* sV, float (&ta)[RPW], float (&tb)[RPW], float (&td)[RPW],
+                                           unsigned tid = threadIdx.x)
 {
+    using fv = typename FVec<RPW>::type;
     constexpr int GW_ = 74;
     const int lane = tid & 63, w = tid >> 6;
     auto vpass = [&](int x, int rg) {
-        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
+        float va[RPW], vb[RPW], vd[RPW];
 #pragma unroll
-        for (int t = 0; t < 14; t++) {
+        for (int r = 0; r < RPW; r++) { va[r] = 0.f; vb[r] = 0.f; vd[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < RPW + 10; t++) {
             float pa, pb, pd;
-            grad_products(sG + (4 * rg + t) * GW_ + x, pa, pb, pd);
+            grad_products(sG + (RPW * rg + t) * GW_ + x, pa, pb, pd);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < RPW; r++) {
                 const int i = t - r;
                 if (i >= 0 && i < 11) {
                     va[r] = __builtin_fmaf(S.us[i], pa, va[r]);
@@ -178,51 +185,63 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* s
                 }
             }
         }
-        sV[(0 * 4 + rg) * GW_ + x] = make_float4(va[0], va[1], va[2], va[3]);
-        sV[(1 * 4 + rg) * GW_ + x] = make_float4(vb[0], vb[1], vb[2], vb[3]);
-        sV[(2 * 4 + rg) * GW_ + x] = make_float4(vd[0], vd[1], vd[2], vd[3]);
+        fv oa, ob, od;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) { oa[r] = va[r]; ob[r] = vb[r]; od[r] = vd[r]; }
+        sV[(0 * 4 + rg) * GW_ + x] = oa;
+        sV[(1 * 4 + rg) * GW_ + x] = ob;
+        sV[(2 * 4 + rg) * GW_ + x] = od;
     };
     vpass(lane, w);
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
-    // software-pipelined by hand (next column's three float4 in flight during this column's 12 FMAs) and fenced per
+    for (int r = 0; r < RPW; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
+    // software-pipelined by hand (next column's three vectors in flight during this column's FMAs) and fenced per
     // column: left alone, the scheduler issues all 33 loads first and sinks the FMAs into the hash code -- 132 live VGPRs
-    float4 xa = sV[(0 * 4 + w) * GW_ + lane], xb = sV[(1 * 4 + w) * GW_ + lane], xd = sV[(2 * 4 + w) * GW_ + lane];
+    fv xa = sV[(0 * 4 + w) * GW_ + lane], xb = sV[(1 * 4 + w) * GW_ + lane], xd = sV[(2 * 4 + w) * GW_ + lane];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
-        float4 na = xa, nb = xb, nd = xd;
+        fv na = xa, nb = xb, nd = xd;
         if (k < 10) {
             na = sV[(0 * 4 + w) * GW_ + lane + k + 1];
             nb = sV[(1 * 4 + w) * GW_ + lane + k + 1];
             nd = sV[(2 * 4 + w) * GW_ + lane + k + 1];
         }
         const float uk = S.us[k];
-        ta[0] = __builtin_fmaf(uk, xa.x, ta[0]); ta[1] = __builtin_fmaf(uk, xa.y, ta[1]); ta[2] = __builtin_fmaf(uk, xa.z, ta[2]); ta[3] = __builtin_fmaf(uk, xa.w, ta[3]);
-        tb[0] = __builtin_fmaf(uk, xb.x, tb[0]); tb[1] = __builtin_fmaf(uk, xb.y, tb[1]); tb[2] = __builtin_fmaf(uk, xb.z, tb[2]); tb[3] = __builtin_fmaf(uk, xb.w, tb[3]);
-        td[0] = __builtin_fmaf(uk, xd.x, td[0]); td[1] = __builtin_fmaf(uk, xd.y, td[1]); td[2] = __builtin_fmaf(uk, xd.z, td[2]); td[3] = __builtin_fmaf(uk, xd.w, td[3]);
+#pragma unroll
+        for (int r = 0; r < RPW; r++) ta[r] = __builtin_fmaf(uk, xa[r], ta[r]);
+#pragma unroll
+        for (int r = 0; r < RPW; r++) tb[r] = __builtin_fmaf(uk, xb[r], tb[r]);
+#pragma unroll
+        for (int r = 0; r < RPW; r++) td[r] = __builtin_fmaf(uk, xd[r], td[r]);
         xa = na; xb = nb; xd = nd;
         __builtin_amdgcn_sched_barrier(0);
     }
-    // pin the 12 sums here: otherwise LLVM sinks the FMAs of rows 1..3 into the per-pixel hash code and keeps (spills) the loaded columns
+    // pin the sums here: otherwise LLVM sinks the FMAs of rows 1.. into the per-pixel hash code and keeps (spills) the loaded columns
 #pragma unroll
-    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(ta[r]), "+v"(tb[r]), "+v"(td[r]));
+    for (int r = 0; r < RPW; r++) asm volatile("" : "+v"(ta[r]), "+v"(tb[r]), "+v"(td[r]));
+}
+
+template <typename GT>
+__device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* sV, float (&ta)[4], float (&tb)[4], float (&td)[4], unsigned tid = threadIdx.x)
+{
+    tensor_acN<4, GT>(S, sG, reinterpret_cast<typename FVec<4>::type*>(sV), ta, tb, td, tid);
 }
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
 constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilter_ac: more uncertain pixels -> the whole tile takes the exact routine
-template <int LW, typename GT>
-__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, float4* sV,
+template <int LW, typename GT, int RPW = 4>
+__device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, typename FVec<RPW>::type* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
                                               int c0, int r0, unsigned tid = threadIdx.x)
 {
     constexpr int GW_ = 74, TW = 64;
     const int lane = tid & 63, w = tid >> 6;
     if (tid == 0) sCnt[0] = 0;
-    float ta[4], tb[4], td[4];
-    tensor_ac(S, sG, sV, ta, tb, td, tid);
+    float ta[RPW], tb[RPW], td[RPW];
+    tensor_acN<RPW, GT>(S, sG, sV, ta, tb, td, tid);
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
@@ -230,8 +249,8 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
     unsigned nUnc = 0, certbits = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int prow = 4 * w + j;
+    for (int j = 0; j < RPW; j++) {
+        const int prow = RPW * w + j;
         const int r = r0 + prow;
         const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
         unsigned bucket;
@@ -290,11 +309,11 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     } else {
         // long list (synthetic content, self-check mode): the whole tile through the all-exact routine (hash_phase; it
         // rebuilds the gradient tile from the LR window), every wave busy.  The AVX2 flavour takes its out-of-line path.
-        unsigned hA[4], hB[4];
-        hash_phase<4, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB, tid);
+        unsigned hA[RPW], hB[RPW];
+        hash_phase<RPW, false, LW, GT>(P, gw, sL, sG, sTab, nullptr, c0, r0, hA, hB, tid);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int prow = 4 * w + j;
+        for (int j = 0; j < RPW; j++) {
+            const int prow = RPW * w + j;
             if (hA[j] != 0xFFu && ((certbits >> j) & 1u) &&
                 (sH[prow * TW + lane] != (uint8_t)hA[j] || (hB[j] != 0xFFu && sH2[prow * TW + lane] != (uint8_t)hB[j]))) bad++;
             sH[prow * TW + lane] = (uint8_t)hA[j];

@@ -12,6 +12,8 @@ struct ResizeParams {
     int spitch, dpitch;          // in elements
     int Sx, Dx, Sy, Dy;          // reduced ratios
     int tie_even;
+    int sstep, dstep;            // samples between horizontally adjacent samples of the plane (1; 2 = one channel of an interleaved
+                                 // two-channel plane: the UV plane of NV12 / P010); pitches stay in samples of the container
     int narrow;                  // 1: the 32-bit path of k_resize is exact for this geometry (make_resize)
     float rdenx, rdeny, rden2;   // 1 / (2 Dx), 1 / (2 Dy), 1 / (2 * 2 Dx * 2 Dy)
 };
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
         const unsigned denx = 2u * (unsigned)R.Dx, deny = 2u * (unsigned)R.Dy;
         const TIn* r0 = src + (size_t)y0 * R.spitch;
         const TIn* r1 = src + (size_t)y1 * R.spitch;
+        x0 *= R.sstep; x1 *= R.sstep;
         const unsigned top = (denx - (unsigned)fx) * (unsigned)r0[x0] + (unsigned)fx * (unsigned)r0[x1];
         const unsigned bot = (denx - (unsigned)fx) * (unsigned)r1[x0] + (unsigned)fx * (unsigned)r1[x1];
         const unsigned num = (deny - (unsigned)fy) * top + (unsigned)fy * bot;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
         const unsigned t = 2u * num + den;
         unsigned q = div_small(t, 2u * den, R.rden2);
         if (R.tie_even && (t - q * 2u * den == 0u) && (q & 1u)) q--;
-        dst[(size_t)y * R.dpitch + x] = (TOut)q;
+        dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)q;
         return;
     }
     int x0, x1, fx, y0, y1, fy;
@@ -81,13 +84,14 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
     const long long denx = 2 * R.Dx, deny = 2 * R.Dy;
     const TIn* r0 = src + (size_t)y0 * R.spitch;
     const TIn* r1 = src + (size_t)y1 * R.spitch;
+    x0 *= R.sstep; x1 *= R.sstep;
     const long long top = (denx - fx) * (long long)r0[x0] + (long long)fx * r0[x1];
     const long long bot = (denx - fx) * (long long)r1[x0] + (long long)fx * r1[x1];
     const long long num = (deny - fy) * top + fy * bot;
     const long long den = denx * deny;
     long long q = (2 * num + den) / (2 * den);
     if (R.tie_even && ((2 * num + den) % (2 * den) == 0) && (q & 1)) q--;
-    dst[(size_t)y * R.dpitch + x] = (TOut)q;
+    dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)q;
 }
 
 // 2x special case of the same arithmetic: weights {1,3}/4 per axis, out = (sum + 8) >> 4

@@ -531,7 +531,8 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
             if (i == 2 || i == 5) {            // RNLSetRes never looked at the Cb planes: they must match Cr
                 if (pl[i]->width != pl[i - 1]->width || pl[i]->height != pl[i - 1]->height) return RNLErrorBadParameter;
             } else if (pl[i]->width != G.geo[i][0] || pl[i]->height != G.geo[i][1]) return RNLErrorBadParameter;
-            if ((uint64_t)pl[i]->step < (uint64_t)pl[i]->width * bps) return RNLErrorBadParameter;
+            const unsigned per = (i != 0 && i != 3 && (pl[i]->bitShift & RAISR_HIP_INTERLEAVED2)) ? 2u : 1u;
+            if ((uint64_t)pl[i]->step < (uint64_t)pl[i]->width * bps * per) return RNLErrorBadParameter;
         }
     }
     auto failed = [&]() {
@@ -540,6 +541,7 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
     };
     const size_t K = G.yBands.size();
     if (!G.external) {
+        if ((inCr->bitShift | inCb->bitShift | outCr->bitShift | outCb->bitShift) & RAISR_HIP_INTERLEAVED2) return RNLErrorBadParameter;   // device frames only
         VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
         pinPlanes(pl);
     }
@@ -547,9 +549,12 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         // planes are device pointers: RAISR on Y and the cheap upscale of both chroma planes without leaving HBM
         if (inCr->step != inCb->step || outCr->step != outCb->step) return RNLErrorBadParameter;
         if (raisr_hip_set_blending(G.ctx, (int)blendingMode) != RAISR_HIP_OK) return RNLErrorBadParameter;
-        int rc = raisr_hip_process_frame_device(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
-                                                inCr->pData, inCb->pData, inCr->step, outCr->pData, outCb->pData, outCr->step,
-                                                (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height, G.externalStream);
+        // NV12 / P010 surfaces: both chroma descriptors flag one interleaved plane (RaisrDefaults.h) -- all four or none
+        const unsigned il = (inCr->bitShift & inCb->bitShift & outCr->bitShift & outCb->bitShift) & RAISR_HIP_INTERLEAVED2;
+        if (((inCr->bitShift | inCb->bitShift | outCr->bitShift | outCb->bitShift) & RAISR_HIP_INTERLEAVED2) && !il) return RNLErrorBadParameter;
+        int rc = raisr_hip_process_frame_device_ex(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
+                                                   inCr->pData, inCb->pData, inCr->step, outCr->pData, outCb->pData, outCr->step,
+                                                   (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height, il ? 2 : 1, G.externalStream);
         if (rc == RAISR_HIP_OK && !G.externalStream) rc = raisr_hip_synchronize(G.ctx);
         return rc != RAISR_HIP_OK ? failed() : RNLErrorNone;
     }
