@@ -415,7 +415,8 @@ def end_to_end_leg(R, wl, n_frames, gpu):
         R.RNLHandler_Deinit()
     fps = n_frames / dt
     return {"value": round(fps * wl.out_w * wl.out_h / 1e6, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
-            "what": "host->host yuv420p through RNLHandler_Process (synchronous, pageable caller planes, Y+U+V, PCIe inclusive)"}
+            "what": "host->host yuv420p through RNLHandler_Process (synchronous, one call per frame; ordinary malloc'ed caller planes, which the library "
+                    "page-locks on first sight; last pass in 3 row ranges with the finished rows downloaded early; Y+U+V, PCIe inclusive)"}
 
 
 def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):

@@ -183,6 +183,7 @@ int raisr_hip_process_host_async(raisr_hip_ctx *ctx,
  * of consecutive frames each run back to back, in frame order, with device-side events between the stages.
  * raisr_hip_synchronize() then waits for that context's last frame only.  The streams must outlive their use by the context. */
 int  raisr_hip_use_streams(raisr_hip_ctx *ctx, void *compute, void *upload, void *download);
+int  raisr_hip_set_chunks(raisr_hip_ctx *ctx, int n);               /* host-plane entry: last pass in n row ranges, finished rows downloaded early (1..8) */
 int  raisr_hip_set_after(raisr_hip_ctx *ctx, raisr_hip_ctx *prev);   /* bands of one frame: ctx's Y kernels (host-plane entry) start after prev's */
 
 typedef struct raisr_hip_stream raisr_hip_stream;

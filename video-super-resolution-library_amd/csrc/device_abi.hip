@@ -1121,6 +1121,16 @@ int raisr_hip_synchronize(raisr_hip_ctx* c)
     return RAISR_HIP_OK;
 }
 
+// Host-plane entry, whole frames: run the last pass in n row ranges and download every finished range while the next one is
+// computed (1 = one download after the frame).  Pays only with page-locked caller planes (a pageable download blocks the
+// calling thread); RAISR_HIP_CHUNKS overrides.
+int raisr_hip_set_chunks(raisr_hip_ctx* c, int n)
+{
+    if (!c || n < 1 || n > 8) return fail(RAISR_HIP_EINVAL, "chunks must be 1..8");
+    if (!getenv("RAISR_HIP_CHUNKS")) c->chunks = n;
+    return RAISR_HIP_OK;
+}
+
 // Order this context's Y kernels (host-plane entry) after those of `prev` (NULL: no ordering).  Both contexts on one device.
 int raisr_hip_set_after(raisr_hip_ctx* c, raisr_hip_ctx* prev)
 {
