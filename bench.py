@@ -193,11 +193,12 @@ def cpu_baseline(wl, sample_frames):
 
 
 def source_hash():
-    """sha256 over the kernel sources: a committed PMC traffic figure is only quoted for the kernels it was measured on."""
+    """sha256 over the device code and its launch logic (csrc/*.hip, csrc/*.h; not the plugin layer's *.cpp): a committed PMC
+    traffic figure is only quoted for the kernels it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h", ".cpp")):
+        if fn.endswith((".hip", ".h")):
             h.update(fn.encode())
             h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()
@@ -386,37 +387,62 @@ class _stdout_to_stderr:
 
 def end_to_end_leg(R, wl, n_frames, gpu):
     """Reference methodology (docs/performance.md:8-13): host yuv planes in, host yuv planes out, one synchronous
-    RNLHandler_Process per frame, Y + U + V, PCIe inclusive."""
+    RNLHandler_Process per frame, Y + U + V, PCIe inclusive.  Measured twice: with frame buffers from RNLHandler_HostAlloc (what the
+    buffer pools of ffmpeg/vf_raisr_hip.diff hand to the filter) and with ordinary numpy (malloc'ed, pageable) planes."""
     import synth
     ratio = wl.out_w / wl.in_w
-    ys = wl.frames("natural", range(4))
+    ys_np = wl.frames("natural", range(4))
     cw, ch = wl.in_w // 2, wl.in_h // 2
-    u = synth.chroma(cw, ch, wl.bits)
-    v = synth.chroma(cw, ch, wl.bits)
-    oy = np.zeros((wl.out_h, wl.out_w), ys[0].dtype)
-    ou = np.zeros((int(ch * ratio), int(cw * ratio)), u.dtype)
-    ov = np.zeros_like(ou)
-    R.RNLHandler_SetOpenCLContext(0, gpu)
-    with _stdout_to_stderr():
-        rc = R.RNLHandler_Init(wl.folder, ratio, wl.bits, R.VideoRange, 20, R.HIP if wl.asm == 2 else wl.asm, wl.passes, wl.mode)
-    if rc != R.RNLErrorNone:
-        raise RuntimeError(f"RNLHandler_Init rc={rc:#x}")
-    try:
-        if R.RNLHandler_SetRes((ys[0], u, v), (oy, ou, ov)) != R.RNLErrorNone:
-            raise RuntimeError("RNLHandler_SetRes failed")
-        for i in range(8):
-            R.RNLHandler_Process((ys[i % 4], u, v), (oy, ou, ov))
-        t0 = time.perf_counter()
-        for i in range(n_frames):
-            if R.RNLHandler_Process((ys[i % 4], u, v), (oy, ou, ov)) != R.RNLErrorNone:
-                raise RuntimeError("RNLHandler_Process failed")
-        dt = time.perf_counter() - t0
-    finally:
-        R.RNLHandler_Deinit()
-    fps = n_frames / dt
-    return {"value": round(fps * wl.out_w * wl.out_h / 1e6, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
-            "what": "host->host yuv420p through RNLHandler_Process (synchronous, one call per frame; ordinary malloc'ed caller planes, which the library "
-                    "page-locks on first sight; last pass in 3 row ranges with the finished rows downloaded early; Y+U+V, PCIe inclusive)"}
+    ocw, och = int(cw * ratio), int(ch * ratio)
+    dt_ = ys_np[0].dtype
+    u_np = synth.chroma(cw, ch, wl.bits)
+    v_np = synth.chroma(cw, ch, wl.bits)
+
+    def run(alloc):
+        keep = []
+
+        def plane(shape, fill=None):
+            if alloc == "host_alloc":
+                hp = R.HostPlane(shape, dt_)
+                keep.append(hp)
+                a = hp.array
+            else:
+                a = np.empty(shape, dt_)
+            a[...] = 0 if fill is None else fill
+            return a
+        ys = [plane(y.shape, y) for y in ys_np]
+        u, v = plane((ch, cw), u_np), plane((ch, cw), v_np)
+        oy, ou, ov = plane((wl.out_h, wl.out_w)), plane((och, ocw)), plane((och, ocw))
+        R.RNLHandler_SetOpenCLContext(0, gpu)
+        with _stdout_to_stderr():
+            rc = R.RNLHandler_Init(wl.folder, ratio, wl.bits, R.VideoRange, 20, R.HIP if wl.asm == 2 else wl.asm, wl.passes, wl.mode)
+        if rc != R.RNLErrorNone:
+            raise RuntimeError(f"RNLHandler_Init rc={rc:#x}")
+        try:
+            if R.RNLHandler_SetRes((ys[0], u, v), (oy, ou, ov)) != R.RNLErrorNone:
+                raise RuntimeError("RNLHandler_SetRes failed")
+            for i in range(8):
+                R.RNLHandler_Process((ys[i % 4], u, v), (oy, ou, ov))
+            t0 = time.perf_counter()
+            for i in range(n_frames):
+                if R.RNLHandler_Process((ys[i % 4], u, v), (oy, ou, ov)) != R.RNLErrorNone:
+                    raise RuntimeError("RNLHandler_Process failed")
+            return n_frames / (time.perf_counter() - t0)
+        finally:
+            R.RNLHandler_Deinit()
+            for hp in keep:
+                hp.close()
+    fps = run("host_alloc")
+    fps_pageable = run("malloc")
+    mp = wl.out_w * wl.out_h / 1e6
+    return {"value": round(fps * mp, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
+            "what": "host->host yuv420p through RNLHandler_Process (synchronous, one call per frame; frame buffers from RNLHandler_HostAlloc, as the "
+                    "FFmpeg filter's pools provide them: page-locked, so the last pass runs in 3 row ranges with the finished rows downloaded early; "
+                    "Y+U+V, PCIe inclusive)",
+            "pageable_planes": {"value": round(fps_pageable * mp, 2), "unit": "MP/s", "fps": round(fps_pageable, 2),
+                                "what": "the same with ordinary malloc'ed planes: carried through the library's own page-locked bounce memory "
+                                        "(rows packed / unpacked by 4 threads, range by range; csrc/host_copy.h) -- the library never hands pageable "
+                                        "memory to an asynchronous copy and never page-locks memory it does not own unless RAISR_HIP_PIN=1"}}
 
 
 def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):

@@ -61,4 +61,8 @@ RNLERRORTYPE RNLSubmit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType 
 RNLERRORTYPE RNLCollect();
 int RNLFramesInFlight();
 
+/* Page-locked frame memory (extension, see RaisrHandler.h). */
+void *RNLHostAlloc(size_t bytes);
+void RNLHostFree(void *p);
+
 #endif /* RAISR_H */

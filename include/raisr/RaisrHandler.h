@@ -17,6 +17,7 @@
 #ifndef RAISR_HANDLER_H
 #define RAISR_HANDLER_H
 
+#include <stddef.h>
 #include "RaisrDefaults.h"
 
 #ifdef __cplusplus
@@ -61,6 +62,17 @@ RNLERRORTYPE RNLHandler_Submit(VideoDataType *srcY, VideoDataType *srcCr, VideoD
                                BlendingMode blend);
 RNLERRORTYPE RNLHandler_Collect(void);
 int RNLHandler_FramesInFlight(void);
+
+/*
+ * Page-locked frame memory -- EXTENSION.  A copy from or to pageable memory is staged by the HIP runtime on the calling thread;
+ * on page-locked memory it is a DMA that runs next to the kernels.  A host that takes its frame buffers from here (FFmpeg: the
+ * buffer pools ffmpeg/vf_raisr_hip.diff installs) gets that without the library ever touching memory it does not own:
+ * Process recognises page-locked planes and then returns finished rows while later rows are computed; Submit / Collect overlap
+ * whole frames.  Ordinary (malloc'ed) planes keep working everywhere, at the staged rate.  HostFree may be called at any time,
+ * also after Deinit; NULL is ignored.
+ */
+void *RNLHandler_HostAlloc(size_t bytes);
+void RNLHandler_HostFree(void *p);
 
 #ifdef __cplusplus
 }

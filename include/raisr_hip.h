@@ -209,6 +209,7 @@ void *raisr_hip_host_alloc(size_t bytes);            /* page-locked host memory 
 void raisr_hip_host_free(void *p);
 int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the caller already owns; RAISR_HIP_ESTATE: (part of) the range is page-locked already */
 int  raisr_hip_host_unregister(void *p);
+int  raisr_hip_host_is_page_locked(const void *p); /* 1: p lies in memory from raisr_hip_host_alloc / hipHostMalloc or in a registered range; 0: pageable (or not host memory) */
 
 /* NON-bit-exact fast mode (north_star's MFMA question; off by default, RAISR_HIP_FAST=1 turns it on at
  * create time).  The buckets stay exact (certified hash stage); the 121-tap dot product of DotProdPatch_AVX512_32f

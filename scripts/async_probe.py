@@ -8,10 +8,25 @@ import raisr_hip as R, synth
 w, h = 1920, 1080
 fold = os.path.join(ROOT, "filters_2x", "filters_highres")
 n = 600
-ys = [synth.natural_y(w, h, 8, seed=i) for i in range(4)]
-u = synth.chroma(w // 2, h // 2, 8); v = u.copy()
+HOSTALLOC = int(os.environ.get("HOSTALLOC", "1"))         # 1: frame buffers from RNLHandler_HostAlloc (the FFmpeg filter's pools); 0: numpy
+keep = []
+
+
+def plane(shape, fill=None):
+    if HOSTALLOC:
+        keep.append(R.HostPlane(shape, np.uint8))
+        a = keep[-1].array
+    else:
+        a = np.zeros(shape, np.uint8)
+    if fill is not None:
+        a[...] = fill
+    return a
+
+
+ys = [plane((h, w), synth.natural_y(w, h, 8, seed=i)) for i in range(4)]
+u = plane((h // 2, w // 2), synth.chroma(w // 2, h // 2, 8)); v = plane((h // 2, w // 2), u)
 for depth in (1, 2, 3, 4):
-    outs = [(np.zeros((2 * h, 2 * w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)) for _ in range(depth)]
+    outs = [(plane((2 * h, 2 * w)), plane((h, w)), plane((h, w))) for _ in range(depth)]
     R.RNLHandler_SetOpenCLContext(0, 0)
     assert R.RNLHandler_Init(fold, 2.0, 8, R.VideoRange, 20, R.HIP, 1, 1) == 0
     assert R.RNLHandler_SetRes((ys[0], u, v), outs[0]) == 0
@@ -27,4 +42,4 @@ for depth in (1, 2, 3, 4):
             assert R.RNLHandler_Collect() == 0
         dt = time.perf_counter() - t0
     R.RNLHandler_Deinit()
-    print(f"async depth {depth}: {n / dt:.0f} fps ({dt / n * 1e6:.0f} us/frame)", file=sys.stderr)
+    print(f"hostalloc={HOSTALLOC} async depth {depth}: {n / dt:.0f} fps ({dt / n * 1e6:.0f} us/frame)", file=sys.stderr)

@@ -15,7 +15,7 @@
 #define AVFILTER_FLAG_SUPPORT_TIMELINE_GENERIC (1 << 16)
 enum AVMediaType { AVMEDIA_TYPE_VIDEO };
 void av_log(void *avcl, int level, const char *fmt, ...);
-typedef struct AVFrame { unsigned char *data[8]; int linesize[8]; int width, height, format; AVBufferRef *hw_frames_ctx; } AVFrame;
+typedef struct AVFrame { unsigned char *data[8]; int linesize[8]; unsigned char **extended_data; int width, height, format; AVBufferRef *buf[8]; AVBufferRef *hw_frames_ctx; } AVFrame;
 AVFrame *av_frame_alloc(void);
 void av_frame_free(AVFrame **f);
 int av_frame_copy_props(AVFrame *dst, const AVFrame *src);
@@ -23,7 +23,8 @@ struct AVFilterContext; struct AVFilterLink;
 typedef struct AVFilterLink { struct AVFilterContext *src, *dst; int w, h, format; AVBufferRef *hw_frames_ctx; } AVFilterLink;
 typedef struct AVFilterContext { void *priv; AVFilterLink **inputs, **outputs; } AVFilterContext;
 typedef struct AVFilterPad { const char *name; enum AVMediaType type; int (*config_props)(AVFilterLink *);
-    int (*filter_frame)(AVFilterLink *, AVFrame *); int (*request_frame)(AVFilterLink *); } AVFilterPad;
+    int (*filter_frame)(AVFilterLink *, AVFrame *); int (*request_frame)(AVFilterLink *);
+    union { AVFrame *(*video)(AVFilterLink *link, int w, int h); } get_buffer; } AVFilterPad;
 typedef struct AVFilterFormats AVFilterFormats;
 typedef struct AVFilter { const char *name, *description; int priv_size; int (*init)(AVFilterContext *); void (*uninit)(AVFilterContext *);
     const enum AVPixelFormat *pix_fmts; const AVFilterPad *inputs, *outputs; const AVClass *priv_class; int flags, flags_internal; enum AVPixelFormat single_pixfmt; } AVFilter;

@@ -36,6 +36,11 @@ def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_pat
     for needle in ('{"async",', "RNLHandler_SetAsyncDepth(raisr->async)", "RNLHandler_Submit(", "RNLHandler_Collect()",
                    ".request_frame = request_frame", "ret == AVERROR_EOF && raisr->q_count > 0", "collect_oldest(ctx, 0)"):
         assert needle in src, needle
+    # pinned=1: input and output frames from buffer pools over the library's page-locked allocator (the buffer owns the memory:
+    # nothing is page-locked behind FFmpeg's back, nothing outlives its buffer)
+    for needle in ('{"pinned",', "RNLHandler_HostAlloc(size)", "RNLHandler_HostFree(data)", "av_buffer_pool_init2(size, NULL, pinned_buffer_alloc, NULL)",
+                   ".get_buffer.video = get_video_buffer_input", "av_buffer_pool_uninit(&raisr->pool_out)"):
+        assert needle in src, needle
     cc = shutil.which("gcc") or shutil.which("cc")
     out = subprocess.run([cc, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wno-unused-variable", "-Wno-declaration-after-statement",
                           "-I", os.path.join(ROOT, "tests", "ffmpeg_stub"), "-I", os.path.join(ROOT, "include"),

@@ -1,5 +1,7 @@
 """-m gpu: the reference plugin API (RNLHandler_*) end to end on the GPU -- vf_raisr's call protocol,
 chroma planes, row steps larger than the width, repeated frames, re-init -- against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -358,65 +360,97 @@ def test_async_submit_collect_frames_equal_the_oracle_in_order(bits, asm, passes
         assert R.RNLHandler_Deinit() == 0
 
 
-def test_registered_planes_survive_free_and_reuse():
-    """RNLProcess page-locks the caller's planes on first sight and remembers them (csrc/raisr_api.cpp: PinCache).  A host may
-    free a buffer and get the same addresses back from its allocator with different pages behind them: the remembered
-    registration must not make a later frame read or write stale pages.  Frames from freshly allocated, freed and
-    re-allocated planes (malloc returns the same addresses for same-sized blocks) against the oracle, many times; then more
-    distinct buffers than the cache holds."""
+def test_opt_in_pin_cache_with_recycled_and_many_live_buffers(monkeypatch):
+    """RAISR_HIP_PIN=1 (opt-in; the host keeps every plane buffer allocated until RNLHandler_Deinit): RNLProcess page-locks the
+    caller's planes on first sight and remembers them (csrc/raisr_api.cpp: PinCache).  Frames through a recycled pool of
+    malloc'ed buffers against the oracle; then more live buffers than the cache holds (48): the least recently used
+    registrations are dropped and nothing breaks.  Buffers are freed only after Deinit."""
     import ctypes
     import raisr_hip as R
     import synth
+    monkeypatch.setenv("RAISR_HIP_PIN", "1")
     libc = ctypes.CDLL(None)
     libc.malloc.restype = ctypes.c_void_p
     libc.malloc.argtypes = [ctypes.c_size_t]
     libc.free.argtypes = [ctypes.c_void_p]
-    w, h = 480, 272                                      # planes above the cache's 64 KB threshold and above malloc's mmap threshold
+    w, h = 480, 272                                      # planes above the cache's 64 KB threshold
     fold = "filters_2x/filters_highres"
     case = ("x", fold, (2, 1), 8, 1, 1, 2, False)
     ys = [synth.natural_y(w, h, 8, seed=500 + s) for s in range(4)]
     refs = [oracle_y(y, case) for y in ys]
     c = synth.chroma(w // 2, h // 2, 8)
+    live = []
 
     def plane(shape):
         n = shape[0] * shape[1]
         p = libc.malloc(n)
-        a = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p)).reshape(shape)
-        return p, a
+        live.append(p)
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p)).reshape(shape)
+
+    def frame_set():
+        return (plane((h, w)), plane((h // 2, w // 2))), (plane((2 * h, 2 * w)), plane((h, w)), plane((h, w)))
     assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
     assert R.RNLHandler_Init(folder(fold), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
     try:
-        seen = set()
-        first = True
+        pool = [frame_set() for _ in range(3)]
+        for (ay, au), _ in pool:
+            au[...] = c
+        assert R.RNLHandler_SetRes((pool[0][0][0], pool[0][0][1], pool[0][0][1]), pool[0][1]) == 0
         for it in range(24):
-            py, ay = plane((h, w)); po, ao = plane((2 * h, 2 * w))
-            pu, au = plane((h // 2, w // 2)); pou, aou = plane((h, w)); pov, aov = plane((h, w))
-            seen.add((py, po))
-            ay[...] = ys[it % 4]; au[...] = c; ao[...] = 0
-            if first:
-                assert R.RNLHandler_SetRes((ay, au, au), (ao, aou, aov)) == 0
-                first = False
+            (ay, au), (ao, aou, aov) = pool[it % 3]
+            ay[...] = ys[it % 4]; ao[...] = 0
+            assert R.lib().raisr_hip_host_is_page_locked(ay.ctypes.data) == (1 if it >= 3 else 0)
             assert R.RNLHandler_Process((ay, au, au), (ao, aou, aov)) == 0
             assert np.array_equal(ao, refs[it % 4]), (it, int((ao != refs[it % 4]).sum()))
-            for p in (py, po, pu, pou, pov):
-                libc.free(p)
-        # more live buffers than the cache has entries (48): the oldest registrations are dropped, nothing breaks
-        live = []
-        for it in range(60):
-            py, ay = plane((h, w)); po, ao = plane((2 * h, 2 * w))
-            live.append((py, po))
-            ay[...] = ys[it % 4]
-            pu, au = plane((h // 2, w // 2)); au[...] = c
-            pou, aou = plane((h, w)); pov, aov = plane((h, w))
-            live.append((pu, pou)); live.append((pov, pov))
+        for it in range(20):                             # 20 x 5 planes above the threshold: more than the cache has entries
+            (ay, au), (ao, aou, aov) = frame_set()
+            ay[...] = ys[it % 4]; au[...] = c
             assert R.RNLHandler_Process((ay, au, au), (ao, aou, aov)) == 0
             assert np.array_equal(ao, refs[it % 4]), ("many buffers", it)
     finally:
         assert R.RNLHandler_Deinit() == 0
-        for a, b in live:
-            libc.free(a)
-            if b != a:
-                libc.free(b)
+        for p in live:
+            libc.free(p)
+
+
+@pytest.mark.parametrize("bits,pad", [(8, 0), (8, 48), (10, 16)])
+def test_planes_from_hostalloc_take_the_page_locked_path(bits, pad):
+    """Frame buffers from RNLHandler_HostAlloc (what ffmpeg/vf_raisr_hip.diff's buffer pools hand to the filter): recognised as
+    page-locked, processed with the last pass in row ranges (no RAISR_HIP_* set), same bits for Y and chroma, with and without
+    row padding; ordinary numpy planes next to them in the same session; freed after Deinit."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h = 322, 190
+    dt = np.uint8 if bits == 8 else np.uint16
+    fold = "filters_2x/filters_highres"
+    ys = [synth.natural_y(w, h, bits, seed=800 + i) for i in range(3)]
+    u = synth.random_y(w // 2, h // 2, bits, seed=7).astype(dt); v = synth.random_y(w // 2, h // 2, bits, seed=8).astype(dt)
+    cw, ch = w // 2, h // 2
+    keep = [R.HostPlane((h, w), dt, w + pad), R.HostPlane((ch, cw), dt, cw + pad), R.HostPlane((ch, cw), dt, cw + pad),
+            R.HostPlane((2 * h, 2 * w), dt, 2 * w + pad), R.HostPlane((2 * ch, 2 * cw), dt, 2 * cw + pad), R.HostPlane((2 * ch, 2 * cw), dt, 2 * cw + pad)]
+    iy, iu, iv, oy, ou, ov = [k.array for k in keep]
+    assert R.lib().raisr_hip_host_is_page_locked(iy.ctypes.data) == 1 and R.lib().raisr_hip_host_is_page_locked(ys[0].ctypes.data) == 0
+    iu[...] = u; iv[...] = v
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, bits, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        assert R.RNLHandler_SetRes((iy, iu, iv), (oy, ou, ov)) == 0
+        for y in ys:
+            iy[...] = y; oy[...] = 0; ou[...] = 0
+            assert R.RNLHandler_Process((iy, iu, iv), (oy, ou, ov)) == 0
+            ref = oracle_y(y, ("x", fold, (2, 1), bits, 1, 1, 2, False))
+            assert np.array_equal(oy, ref)
+            assert np.array_equal(ou, O.resize(u, 2 * cw, 2 * ch).astype(dt)) and np.array_equal(ov, O.resize(v, 2 * cw, 2 * ch).astype(dt))
+            # pageable planes in the same session (mixed: page-locked output, pageable input, and the other way round)
+            oy[...] = 0
+            assert R.RNLHandler_Process((y, u, v), (oy, ou, ov)) == 0 and np.array_equal(oy, ref)
+            noy = np.zeros((2 * h, 2 * w), dt); nou = np.zeros((2 * ch, 2 * cw), dt); nov = np.zeros_like(nou)
+            assert R.RNLHandler_Process((iy, iu, iv), (noy, nou, nov)) == 0 and np.array_equal(noy, ref)
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+        for k in keep:
+            k.close()                                    # after Deinit: allowed
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 4])
@@ -440,7 +474,11 @@ def test_plugin_path_with_row_chunks_and_strided_planes(chunks, monkeypatch):
             assert R.RNLHandler_SetRes((ys[0], u, v), (oy, ou, ov)) == 0
             for y in ys:
                 oy[...] = 0
-                assert R.RNLHandler_Process((_strided(y, 10), u, v), (oy, ou, ov)) == 0
+                yin = _strided(y, 10)                     # a fresh buffer per call, freed right after it: hosts do that
+                if os.environ.get("RAISR_TEST_TRACE_PTRS"):
+                    os.write(1, f"[ptrs] yin={yin.ctypes.data:#x}+{yin.base.nbytes} oy={oy.ctypes.data:#x}+{oy.base.nbytes} ou={ou.ctypes.data:#x} ov={ov.ctypes.data:#x} u={u.ctypes.data:#x}\n".encode())
+                assert R.RNLHandler_Process((yin, u, v), (oy, ou, ov)) == 0
+                del yin
                 assert np.array_equal(oy, oracle_y(y, ("x", fold, (2, 1), 8, passes, 1, 2, False)))
                 assert np.array_equal(ou, O.resize(u, 2 * cw, 2 * ch).astype(np.uint8)) and np.array_equal(ov, O.resize(v, 2 * cw, 2 * ch).astype(np.uint8))
             assert R.RNLHandler_Process((ys[0], u, v), (oy, ou, ov), R.Randomness) == 0           # not chunked: same entry, other blend

@@ -157,9 +157,12 @@ def test_ffmpeg_option_surface_is_the_reference_surface():
     diff = open(os.path.join(ROOT, "ffmpeg", "vf_raisr_hip.diff")).read()
     added = {m[0]: m for m in re.findall(r'^\+\s*\{"(\w+)",\s*"[^"]*",\s*OFFSET\(\w+\),\s*(AV_OPT_TYPE_\w+),\s*\{\.(?:dbl|i64|str)\s*=\s*([^}]*)\},\s*([^,]+),\s*([^,]+),\s*FLAGS\}', diff, re.M)}
     removed = set(re.findall(r'^-\s*\{"(\w+)",', diff, re.M))
-    assert "async" in added and "async" not in names                    # the one new option (frames in flight); the reference has no such name
+    assert "async" in added and "async" not in names                    # new option (frames in flight); the reference has no such name
     assert (added["async"][1], added["async"][2].strip(), added["async"][3].strip()) == ("AV_OPT_TYPE_INT", "0", "0")   # default 0 = the reference's behaviour
     del added["async"]
+    assert "pinned" in added and "pinned" not in names                  # new option (where frame buffers come from): changes no pixel
+    assert (added["pinned"][1], added["pinned"][3].strip(), added["pinned"][4].strip()) == ("AV_OPT_TYPE_INT", "0", "1")
+    del added["pinned"]
     assert removed == set(added), (removed, set(added))
     ref = {o[0]: o for o in opts}
     for name, o in added.items():

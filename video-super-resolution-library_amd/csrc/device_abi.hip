@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/raisr_hip.h"
+#include "host_copy.h"               // RowCopyPool, HostBounce: pageable host planes go through page-locked bounce memory
 #include "x86_approx_tables.h"
 #include "x86_approx_dev.h"
 #include "x86_fp16_tables.h"
@@ -237,6 +238,7 @@ struct raisr_hip_ctx {
     GaussW gauss{};
     // device staging for raisr_hip_process_host
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    HostBounce bounce;                          // page-locked bounce memory for pageable host planes (host_copy.h)
     hipEvent_t ev_chroma = nullptr;             // chroma lane done (packed-frame download waits for it)
     KernelTimer timer;
 };
@@ -731,6 +733,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_kern) (void)hipEventDestroy(c->ev_kern);
     for (hipEvent_t& e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
+    c->bounce.release();
     if (c->own_stream) { c->stream = c->own_stream; c->own_stream = nullptr; }
     if (c->d_gauss) (void)hipFree(c->d_gauss);
     pool_put_stage(c->device, c->d_stage, c->d_stage_bytes);
@@ -1107,6 +1110,7 @@ int raisr_hip_synchronize(raisr_hip_ctx* c)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    if (!c->bounce.unpack.empty()) HIP_TRY(c->bounce.finish());          // downloads into pageable planes: unpack as their copies complete
     if (c->up) {                               // shared streams: wait for this context's last frame only
         if (c->done_pending) { HIP_TRY(hipEventSynchronize(c->ev_done)); c->done_pending = false; }
         if (c->legacy_pending) {               // a banded frame (rows != NULL) went through the context's own stream pair
@@ -1122,7 +1126,8 @@ int raisr_hip_synchronize(raisr_hip_ctx* c)
 }
 
 // Host-plane entry, whole frames: run the last pass in n row ranges and download every finished range while the next one is
-// computed (1 = one download after the frame).  Pays only with page-locked caller planes (a pageable download blocks the
+// computed (1 = one download after the frame).  Page-locked planes: the copy engine writes them directly; pageable planes: the
+// rows of range i are unpacked from the bounce memory while range i+1 is computed (older text: a pageable download blocks the
 // calling thread); RAISR_HIP_CHUNKS overrides.
 int raisr_hip_set_chunks(raisr_hip_ctx* c, int n)
 {
@@ -1210,6 +1215,34 @@ static hipError_t copy_plane(void* dst, size_t dpitch, const void* src, size_t s
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
 }
 
+// One plane (or row range) between the caller's host memory and the device.  Page-locked host memory: an asynchronous copy.
+// Pageable host memory: through the context's bounce memory (host_copy.h) -- packed now (upload) or unpacked when the frame is
+// synchronised (download).  RAISR_HIP_BOUNCE=0 hands pageable memory to the runtime as rounds 1-2 did (A/B measurements only).
+static hipError_t host_copy(raisr_hip_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes, size_t rows,
+                            hipMemcpyKind kind, hipStream_t s)
+{
+    if (!rows || !row_bytes) return hipSuccess;
+    static const bool bounce_on = !(getenv("RAISR_HIP_BOUNCE") && atoi(getenv("RAISR_HIP_BOUNCE")) == 0);
+    const bool h2d = kind == hipMemcpyHostToDevice;
+    const void* hp = h2d ? src : dst;
+    const size_t hpitch = h2d ? spitch : dpitch;
+    if (!bounce_on || HostBounce::page_locked(hp, hpitch * (rows - 1) + row_bytes)) return copy_plane(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
+    char* b = c->bounce.take(row_bytes * rows);
+    if (!b) return hipErrorOutOfMemory;
+    if (h2d) {
+        RowCopyPool::get().copy(b, row_bytes, (const char*)src, spitch, row_bytes, rows);
+        return copy_plane(dst, dpitch, b, row_bytes, row_bytes, rows, kind, s);
+    }
+    hipError_t e = copy_plane(b, row_bytes, src, spitch, row_bytes, rows, kind, s);
+    if (e != hipSuccess) return e;
+    hipEvent_t ev = c->bounce.next_event();
+    if (!ev) return hipErrorOutOfMemory;
+    e = hipEventRecord(ev, s);
+    if (e != hipSuccess) return e;
+    c->bounce.unpack.push_back({(char*)dst, dpitch, b, row_bytes, rows, ev});
+    return hipSuccess;
+}
+
 int raisr_hip_process_host(raisr_hip_ctx* c,
                            const void* in_y, size_t in_y_pitch, void* out_y, size_t out_y_pitch,
                            const void* in_u, size_t in_u_pitch, void* out_u, size_t out_u_pitch,
@@ -1257,18 +1290,23 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     char* d = (char*)c->d_stage;
+    if (do_up) {
+        // room for every plane of the frame in the bounce memory (used only by planes that turn out to be pageable)
+        if (!c->bounce.unpack.empty()) (void)c->bounce.finish();        // a caller that never synchronised the previous frame
+        c->bounce.begin_frame(al(iy) + 2 * al(ic) + 2 * al(oy) + 2 * al(oc) + 16 * 256);
+    }
     if (c->up && !rows) {
         // stage-ordered pipeline of the stream ring: uploads on the shared upload stream, kernels (Y, then the two cheap chroma
         // upscales) on the compute stream, one download on the shared download stream; events carry the dependencies on the device
         const size_t irow = (size_t)g.in_width * bps, orow = (size_t)g.out_width * bps;
         const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
         hipStream_t s = c->stream;
-        HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, c->up));
+        HIP_TRY(host_copy(c, d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, c->up));
         if (c->blending == RAISR_HIP_BLEND_RANDOMNESS)
-            HIP_TRY(copy_plane(d + off_oy, orow, out_y, out_y_pitch, orow, g.out_height, hipMemcpyHostToDevice, c->up));
+            HIP_TRY(host_copy(c, d + off_oy, orow, out_y, out_y_pitch, orow, g.out_height, hipMemcpyHostToDevice, c->up));
         if (chroma) {
-            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
-            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
+            HIP_TRY(host_copy(c, d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
+            HIP_TRY(host_copy(c, d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, c->up));
         }
         // (kept also when upload and compute stream are the same: without this marker and the one before the download the same
         //  ring measures 2.3-3.6 k fps instead of 3.9-4.2 k -- the runtime batches the stream's commands differently)
@@ -1292,12 +1330,12 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         const bool packed = chroma && out_y_pitch == orow && out_u_pitch == crow && out_v_pitch == crow &&
                             (const char*)out_u == (const char*)out_y + (off_ou - off_oy) && (const char*)out_v == (const char*)out_y + (off_ov - off_oy);
         if (packed) {
-            HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, c->down));
+            HIP_TRY(host_copy(c, out_y, (off_ov - off_oy) + oc, d + off_oy, (off_ov - off_oy) + oc, (off_ov - off_oy) + oc, 1, hipMemcpyDeviceToHost, c->down));
         } else {
-            HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy, orow, orow, g.out_height, hipMemcpyDeviceToHost, c->down));
+            HIP_TRY(host_copy(c, out_y, out_y_pitch, d + off_oy, orow, orow, g.out_height, hipMemcpyDeviceToHost, c->down));
             if (chroma) {
-                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
-                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
+                HIP_TRY(host_copy(c, out_u, out_u_pitch, d + off_ou, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
+                HIP_TRY(host_copy(c, out_v, out_v_pitch, d + off_ov, crow, crow, cout_h, hipMemcpyDeviceToHost, c->down));
             }
         }
         HIP_TRY(hipEventRecord(c->ev_done, c->down));
@@ -1312,9 +1350,9 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     const size_t cirow = (size_t)cin_w * bps, crow = (size_t)cout_w * bps;
     bool y_chunked = false;                    // Y rows already on their way back (stage 0 only: upload and download in one call)
     if (do_up) {
-        HIP_TRY(copy_plane(d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
+        HIP_TRY(host_copy(c, d, irow, in_y, in_y_pitch, irow, g.in_height, hipMemcpyHostToDevice, s));
         if (c->blending == RAISR_HIP_BLEND_RANDOMNESS && y_keep > 0)   // pixels the reference leaves untouched keep the caller's bytes
-            HIP_TRY(copy_plane(d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
+            HIP_TRY(host_copy(c, d + off_oy + y_skip * orow, orow, out_y, out_y_pitch, orow, y_keep, hipMemcpyHostToDevice, s));
         if (c->after && c->after->ev_kern_valid) HIP_TRY(hipStreamWaitEvent(s, c->after->ev_kern, 0));
         int rc;
         y_chunked = !rows && do_down && c->chunks > 1 && c->blending != RAISR_HIP_BLEND_RANDOMNESS;
@@ -1322,15 +1360,15 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         if (y_chunked && chroma) {
             // the second stream carries the Y rows back as they are finished: the (cheap) chroma planes go through it first, their
             // download uses the link while nothing else does
-            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
-            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(host_copy(c, d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(host_copy(c, d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
             if (rc) return rc;
             rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
             if (rc) return rc;
             if (c_keep > 0) {
-                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
-                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(host_copy(c, out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(host_copy(c, out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
             }
             chroma_done = true;
         }
@@ -1347,7 +1385,7 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
                 if (cb_err == hipSuccess) cb_err = hipEventRecord(ev, s);
                 if (cb_err == hipSuccess) cb_err = hipStreamWaitEvent(s2, ev, 0);
                 if (cb_err == hipSuccess)
-                    cb_err = copy_plane((char*)out_y + (size_t)r0 * out_y_pitch, out_y_pitch, d + off_oy + (size_t)r0 * orow, orow, orow, (size_t)n, hipMemcpyDeviceToHost, s2);
+                    cb_err = host_copy(c, (char*)out_y + (size_t)r0 * out_y_pitch, out_y_pitch, d + off_oy + (size_t)r0 * orow, orow, orow, (size_t)n, hipMemcpyDeviceToHost, s2);
             };
             rc = process_y_device_impl(c, d, irow, d + off_oy, orow, s, c->chunks, rows_done);
             if (!rc && cb_err != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "chunked download", cb_err);
@@ -1357,8 +1395,8 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
         if (rc) return rc;
         if (c->ev_kern) { HIP_TRY(hipEventRecord(c->ev_kern, s)); c->ev_kern_valid = true; }
         if (chroma && !chroma_done) {
-            HIP_TRY(copy_plane(d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
-            HIP_TRY(copy_plane(d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(host_copy(c, d + off_iu, cirow, in_u, in_u_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
+            HIP_TRY(host_copy(c, d + off_iv, cirow, in_v, in_v_pitch, cirow, cin_h, hipMemcpyHostToDevice, s2));
             rc = raisr_hip_resize_plane_device(c, d + off_iu, cin_w, cin_h, cirow, d + off_ou, cout_w, cout_h, crow, g.bits, s2);
             if (rc) return rc;
             rc = raisr_hip_resize_plane_device(c, d + off_iv, cin_w, cin_h, cirow, d + off_ov, cout_w, cout_h, crow, g.bits, s2);
@@ -1375,13 +1413,13 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
             if (!c->ev_chroma) HIP_TRY(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(c->ev_chroma, s2));
             HIP_TRY(hipStreamWaitEvent(s, c->ev_chroma, 0));
-            HIP_TRY(hipMemcpyAsync(out_y, d + off_oy, (off_ov - off_oy) + oc, hipMemcpyDeviceToHost, s));
+            HIP_TRY(host_copy(c, out_y, (off_ov - off_oy) + oc, d + off_oy, (off_ov - off_oy) + oc, (off_ov - off_oy) + oc, 1, hipMemcpyDeviceToHost, s));
         } else {
             if (chroma && c_keep > 0 && !y_chunked) {
-                HIP_TRY(copy_plane(out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
-                HIP_TRY(copy_plane(out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(host_copy(c, out_u, out_u_pitch, d + off_ou + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(host_copy(c, out_v, out_v_pitch, d + off_ov + c_skip * crow, crow, crow, c_keep, hipMemcpyDeviceToHost, s2));
             }
-            if (y_keep > 0 && !y_chunked) HIP_TRY(copy_plane(out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
+            if (y_keep > 0 && !y_chunked) HIP_TRY(host_copy(c, out_y, out_y_pitch, d + off_oy + y_skip * orow, orow, orow, y_keep, hipMemcpyDeviceToHost, s));
         }
     }
     return RAISR_HIP_OK;

@@ -173,15 +173,20 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
 }
 
 // ---- page-locked caller planes ------------------------------------------------------------------
-// A copy from or to pageable memory is staged by the runtime on the calling thread; a copy on page-locked memory is a DMA the
-// copy engines run next to the kernels.  Hosts like FFmpeg recycle a handful of frame buffers through a pool, so the planes
-// RNLProcess sees are page-locked on first sight and remembered (bounded, least-recently-used region dropped; everything is
-// unlocked in RNLDeinit).  The runtime refuses a copy whose host range is only PARTLY inside a registered range -- so the
-// ranges (exact plane extents, not rounded to pages) are kept disjoint, and a plane that overlaps registered ranges without
-// lying inside one (a band of rows registered first, the whole plane later) gets the union registered as ONE range, after
-// waiting for the frames in flight, whose copies may use the ranges being replaced.  A stale region -- the host freed the buffer and the allocator reused the
-// address -- is harmless on this platform: the driver tracks registered user pages with MMU notifiers and re-validates the
-// range (tests/test_gpu_host_api.py::test_registered_planes_survive_free_and_reuse).  RAISR_HIP_PIN=0 turns the cache off.
+// A copy on page-locked memory is a DMA the copy engines run next to the kernels.  The supported way to get there is memory the
+// host takes from RNLHandler_HostAlloc (FFmpeg: the buffer pools of ffmpeg/vf_raisr_hip.diff); the device layer recognises it
+// per plane (csrc/host_copy.h) and carries pageable planes through page-locked bounce memory of its own -- nothing here touches
+// memory the library does not own.
+//
+// RAISR_HIP_PIN=1 (OPT-IN) additionally page-locks ordinary planes on first sight and remembers the registration (bounded,
+// least-recently-used region dropped; everything is unlocked in RNLDeinit).  The host then promises that every plane buffer it
+// hands over stays allocated until RNLDeinit: a registration outlives a free() of the memory under it, and whatever the
+// allocator puts at that address next is treated as page-locked by the runtime while the driver may already have dropped the
+// mapping (it re-validates user pages about a millisecond after an unmap: a buffer freed and re-allocated faster than that
+// survives, anything else is a GPU page fault).  That is why this is not the default.  The runtime refuses a copy whose host
+// range is only PARTLY inside a registered range -- so the ranges (exact plane extents, not rounded to pages) are kept
+// disjoint, and a plane that overlaps registered ranges without lying inside one (a band of rows registered first, the whole
+// plane later) gets the union registered as ONE range, after waiting for the frames in flight.
 void quiesceDevice();
 
 struct PinCache {
@@ -194,7 +199,7 @@ struct PinCache {
 
     bool on()
     {
-        if (enabled < 0) { const char *e = std::getenv("RAISR_HIP_PIN"); enabled = (e && std::atoi(e) == 0) ? 0 : 1; }
+        if (enabled < 0) { const char *e = std::getenv("RAISR_HIP_PIN"); enabled = (e && std::atoi(e) == 1) ? 1 : 0; }
         return enabled == 1;
     }
     int debug = -1;
@@ -246,11 +251,13 @@ struct PinCache {
     {
         for (Ent &e : ents) if (e.ours) (void)raisr_hip_host_unregister((void *)e.lo);
         ents.clear(); refused.clear();
+        enabled = -1;                                   // the next session reads RAISR_HIP_PIN again
     }
 } gPins;
 
 void pinPlanes(VideoDataType *const pl[6])
 {
+    if (!gPins.on()) return;
     for (int i = 0; i < 6; i++)
         if (pl[i] && pl[i]->pData) gPins.pin(pl[i]->pData, (size_t)pl[i]->step * pl[i]->height);
 }
@@ -511,9 +518,6 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
     } else {
         const int rc = raisr_hip_configure(G.ctx, &cfg);
         if (rc != RAISR_HIP_OK) return failed(rc);
-        // whole frames on one context: with page-locked planes (the pin cache) the rows of the last pass go back in three ranges
-        // while the next range is computed (1080p -> 4K: 2.3 k -> 2.55 k frames/s through this synchronous entry)
-        if (!G.external && gPins.on()) (void)raisr_hip_set_chunks(G.ctx, 3);
     }
     G.resSet = true;
     return RNLErrorNone;
@@ -547,6 +551,10 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         if ((inCr->bitShift | inCb->bitShift | outCr->bitShift | outCb->bitShift) & RAISR_HIP_INTERLEAVED2) return RNLErrorBadParameter;   // device frames only
         VideoDataType *pl[6] = {inY, inCr, inCb, outY, outCr, outCb};
         pinPlanes(pl);
+        // whole frames on one context: the rows of the last pass go back in three ranges while the next range is computed
+        // (1080p -> 4K, page-locked planes: 2.3 k -> 2.55 k frames/s through this synchronous entry; pageable planes: the unpacking
+        // of a range from the bounce memory overlaps the next range's kernels); RAISR_HIP_CHUNKS overrides
+        if (K == 0) (void)raisr_hip_set_chunks(G.ctx, 3);
     }
     if (G.external) {
         // planes are device pointers: RAISR on Y and the cheap upscale of both chroma planes without leaving HBM
@@ -631,6 +639,15 @@ RNLERRORTYPE RNLDeinit()
     gPins.clear();
     return RNLErrorNone;
 }
+
+// ---- page-locked frame memory (extension) -----------------------------------------------------------------------------------
+void *RNLHostAlloc(size_t bytes)
+{
+    if (!bytes) return nullptr;
+    return raisr_hip_host_alloc(bytes);
+}
+
+void RNLHostFree(void *p) { raisr_hip_host_free(p); }
 
 // ---- asynchronous frames (extension; the reference's Process is synchronous, Raisr.cpp:1294-1397) ----------------------------
 // RNLSubmit enqueues a frame on the next lane of a ring (upload, kernels, download: all asynchronous on page-locked planes) and
@@ -748,5 +765,9 @@ RNLERRORTYPE RNLHandler_Submit(VideoDataType *inY, VideoDataType *inU, VideoData
 RNLERRORTYPE RNLHandler_Collect(void) { return RNLCollect(); }
 
 int RNLHandler_FramesInFlight(void) { return RNLFramesInFlight(); }
+
+void *RNLHandler_HostAlloc(size_t bytes) { return RNLHostAlloc(bytes); }
+
+void RNLHandler_HostFree(void *p) { RNLHostFree(p); }
 
 }  // extern "C"

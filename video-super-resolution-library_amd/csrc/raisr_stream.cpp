@@ -7,6 +7,7 @@
 // The library therefore also exports raisr_hip_host_alloc / raisr_hip_host_register so that a host (FFmpeg: a custom
 // get_video_buffer pool) can hand over planes the copy engines read and write directly.  With pageable planes the
 // ring still works, without overlap.
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -209,5 +210,13 @@ int raisr_hip_host_register(void* p, size_t bytes)
     return e == hipErrorHostMemoryAlreadyRegistered ? RAISR_HIP_ESTATE : RAISR_HIP_ERUNTIME;
 }
 int raisr_hip_host_unregister(void* p) { return hipHostUnregister(p) == hipSuccess ? RAISR_HIP_OK : RAISR_HIP_ERUNTIME; }
+int raisr_hip_host_is_page_locked(const void* p)
+{
+    if (!p) return 0;
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }     // ordinary memory: not an error of the caller's
+    return a.type == hipMemoryTypeHost ? 1 : 0;
+}
 
 }  // extern "C"

@@ -122,6 +122,11 @@ def lib():
         L.raisr_hip_host_free.restype = None
         L.raisr_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.raisr_hip_host_unregister.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_host_is_page_locked.argtypes = [ctypes.c_void_p]
+        L.RNLHandler_HostAlloc.argtypes = [ctypes.c_size_t]
+        L.RNLHandler_HostAlloc.restype = ctypes.c_void_p
+        L.RNLHandler_HostFree.argtypes = [ctypes.c_void_p]
+        L.RNLHandler_HostFree.restype = None
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -207,6 +212,33 @@ def RNLHandler_Collect():
 
 def RNLHandler_FramesInFlight():
     return int(lib().RNLHandler_FramesInFlight())
+
+
+class HostPlane:
+    """A 2-D numpy array over page-locked memory from RNLHandler_HostAlloc (the plugin-level allocator a host's frame pool
+    would use); `pitch_elems` > width leaves padding at the end of every row, as pool frames have."""
+
+    def __init__(self, shape, dtype, pitch_elems=None):
+        h, w = shape
+        pitch = w if pitch_elems is None else int(pitch_elems)
+        self.nbytes = h * pitch * np.dtype(dtype).itemsize
+        self._p = lib().RNLHandler_HostAlloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("RNLHandler_HostAlloc failed")
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(h, pitch)[:, :w]
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().RNLHandler_HostFree(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _vdt(a):
