@@ -18,10 +18,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
 and, at N = 1 (outside the timed region of `value`, never mixed into it):
   c3_2pass     -- the same loop for BASELINE.json configs[2] (2-pass: north_star's target configuration)
   end_to_end   -- host planes -> host planes through RNLHandler_Process (Y + both chroma planes, PCIe inclusive:
-                  the reference's own methodology, docs/performance.md:8-13)
+                  the reference's own methodology, docs/performance.md:8-13): frame buffers from RNLHandler_HostAlloc,
+                  and `pageable_planes` for ordinary malloc'ed ones
   stream       -- host planes -> host planes through the library's pinned-ring batch entry (uploads, kernels and
                   downloads of neighbouring frames overlapped)
-  parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR
+  parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR; `certify` = the certified
+                  hash stage's self-check over every benchmarked frame
+  configs      -- BASELINE.json's C1, C3, C4, C5 next to C2: fps, isolated kernel times, both rooflines, self-check
+  frame_kinds  -- C2 on natural / random / constant / 1-px-checkerboard frames (throughput depends on content through the
+                  share of pixels that take the exact hash path)
   fast_mode    -- the opt-in, NOT bit-exact matrix-core filter stage (raisr_hip_set_fast(2)): the same loop, with its
                   distance from the oracle beside it.  Never the headline.
 At N > 1 the line carries `stream` only: every rank streaming host-resident frames through its pinned ring at the same
@@ -734,6 +739,23 @@ def main():
                     except Exception as e:
                         cfgs[cname] = {"value": None, "error": f"{type(e).__name__}: {e}"}
                 extras["configs"] = cfgs
+            if wl.name == "C2" and not args.passes and not args.no_configs:
+                def kinds_leg():
+                    # the certified hash stage makes throughput depend on content (share of pixels that fall back to the exact path):
+                    # the headline's frame kind next to the others, worst case (1-px checkerboard: every tile pays both paths) included
+                    out = {}
+                    for kind in ("natural", "random", "constant", "checker"):
+                        fr = wl.frames(kind, range(4))
+                        n = args.extra_frames
+                        dtk, _, lk, _, _ = device_loop(R, torch, wl, gpu, blobs, args.lanes, fr, n, 1, 1, fence, False)
+                        for d in lk:
+                            d.close()
+                        cert = certify_leg(R, wl, gpu, blobs, fr[:2])
+                        out[kind] = {"fps": round(n / dtk, 2), "value": round(wl.out_w * wl.out_h * n / dtk / 1e6, 2),
+                                     "uncertified_frac": cert.get("uncertified_frac"), "certified_wrong": cert.get("certified_wrong")}
+                    out["what"] = f"C2, {args.extra_frames} frames per kind, {args.lanes} lanes; `value` of this line is the `{args.frame_kind}` kind on {frames_total} frames"
+                    return out
+                leg("frame_kinds", kinds_leg)
             if wl.pixel_types == 4 and wl.bits <= 10 and wl.asm != 5 and hasattr(R.RaisrDevice, "set_fast"):
                 def fast_leg():
                     # NOT a parity path and never the headline: the opt-in matrix-core filter stage, same loop as `value`
