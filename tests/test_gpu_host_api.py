@@ -486,6 +486,58 @@ def test_plugin_path_with_row_chunks_and_strided_planes(chunks, monkeypatch):
             assert R.RNLHandler_Deinit() == 0
 
 
+def test_a_fresh_set_of_pageable_buffers_per_call_and_per_submit():
+    """What an ordinary host does: allocate the frame's planes, call, free them -- every call, contiguous and strided, through the
+    synchronous entry and through Submit / Collect (planes freed right after their Collect).  The bits stay the oracle's; with
+    rounds 1-2's copies (pageable memory handed to asynchronous 2-D copies) this pattern ended in a GPU page fault once in a
+    few hundred calls (csrc/host_copy.h)."""
+    import gc
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h = 322, 181
+    fold = "filters_2x/filters_highres"
+    cw, ch = w // 2, h // 2
+    ys = [synth.natural_y(w, h, 8, seed=900 + i) for i in range(4)]
+    refs = [oracle_y(y, ("x", fold, (2, 1), 8, 1, 1, 2, False)) for y in ys]
+    u0 = synth.random_y(cw, ch, 8, seed=15); v0 = synth.random_y(cw, ch, 8, seed=16)
+    ru, rv = O.resize(u0, 2 * cw, 2 * ch).astype(np.uint8), O.resize(v0, 2 * cw, 2 * ch).astype(np.uint8)
+
+    def fresh(it):
+        pad = (0, 10, 24, 64)[it % 4]
+        mk = (lambda a: _strided(a, pad)) if pad else (lambda a: a.copy())
+        return (mk(ys[it % 4]), mk(u0), mk(v0)), (mk(np.zeros((2 * h, 2 * w), np.uint8)), mk(np.zeros((2 * ch, 2 * cw), np.uint8)), mk(np.zeros((2 * ch, 2 * cw), np.uint8)))
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, 8, R.VideoRange, 20, R.HIP, 1, 1) == 0
+    try:
+        ins, outs = fresh(0)
+        assert R.RNLHandler_SetRes(ins, outs) == 0
+        for it in range(60):
+            ins, outs = fresh(it)
+            assert R.RNLHandler_Process(ins, outs) == 0
+            assert np.array_equal(outs[0], refs[it % 4]) and np.array_equal(outs[1], ru) and np.array_equal(outs[2], rv), it
+            del ins, outs
+            if it % 7 == 0:
+                gc.collect()
+        assert R.RNLHandler_SetAsyncDepth(3) == 0
+        queue = []
+        for it in range(45):
+            if len(queue) == 3:
+                j, ins, outs = queue.pop(0)
+                assert R.RNLHandler_Collect() == 0
+                assert np.array_equal(outs[0], refs[j % 4]) and np.array_equal(outs[1], ru) and np.array_equal(outs[2], rv), j
+                del ins, outs
+            ins, outs = fresh(it)
+            assert R.RNLHandler_Submit(ins, outs) == 0
+            queue.append((it, ins, outs))
+        while queue:
+            j, ins, outs = queue.pop(0)
+            assert R.RNLHandler_Collect() == 0
+            assert np.array_equal(outs[0], refs[j % 4]), j
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+
+
 @pytest.mark.parametrize("bits,ratio", [(8, (2, 1)), (10, (2, 1)), (8, (3, 2))])
 def test_hipexternal_nv12_style_interleaved_chroma(bits, ratio):
     """Device frames as hardware decoders produce them (NV12 / P010: one chroma plane of interleaved (U, V) pairs) -- what
