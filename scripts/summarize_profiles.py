@@ -100,7 +100,7 @@ if pmc:
         hs = hashlib.sha256()
         cs = os.path.join(root, "video-super-resolution-library_amd", "csrc")
         for fn in sorted(os.listdir(cs)):                      # same digest as bench.py source_hash(): the figure is only quoted for these sources
-            if fn.endswith((".hip", ".h")):
+            if fn.endswith((".hip", ".h")) and fn != "host_copy.h":
                 hs.update(fn.encode()); hs.update(open(os.path.join(cs, fn), "rb").read())
         json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic,
                    "source_sha256": hs.hexdigest(), "config": config, "variant_env": variant_env,

@@ -9,6 +9,7 @@
 // BOUNCE memory the context owns: rows are packed into it (upload) or unpacked from it (download, after the copy's event) by a
 // few threads; with the last pass in row ranges the unpacking of range i overlaps the kernels of range i+1.
 #pragma once
+#include <stdint.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -16,6 +17,11 @@
 #include <vector>
 
 // ---- a few persistent threads for row copies -----------------------------------------------------------------------------------
+// One job at a time; its payload is cut into 128 KB blocks that the workers AND the caller claim from one atomic word
+// (job number << 40 | next byte offset), so a worker that wakes up late finds nothing to claim and cannot touch a later job with
+// an old descriptor; the caller returns when every claimed block has been copied (bytes-left counter), not when every worker
+// has checked in.  Workers poll for ~100 us after a job before they sleep on the condition variable: the copies of a frame come
+// in bursts, and a wake-up costs about as much as copying a chroma plane.
 class RowCopyPool {
 public:
     static RowCopyPool& get()
@@ -23,45 +29,46 @@ public:
         static RowCopyPool* p = new RowCopyPool();          // never destroyed: its threads may outlive static destructors
         return *p;
     }
-    // dst[r * dpitch .. + row_bytes) = src[r * spitch .. + row_bytes) for r < rows, cut into blocks the threads (and the caller) take
+    // dst[r * dpitch .. + row_bytes) = src[r * spitch .. + row_bytes) for r < rows
     void copy(char* dst, size_t dpitch, const char* src, size_t spitch, size_t row_bytes, size_t rows)
     {
         if (!rows || !row_bytes) return;
         if (dpitch == row_bytes && spitch == row_bytes) { row_bytes *= rows; rows = 1; dpitch = spitch = row_bytes; }
         const size_t total = row_bytes * rows;
-        if (nthreads_ == 0 || total < ((size_t)256 << 10)) { block(dst, dpitch, src, spitch, row_bytes, rows, 0, total); return; }
-        std::unique_lock<std::mutex> serial(serial_);        // one job at a time (contexts of several lanes share the pool)
+        if (nthreads_ == 0 || total < ((size_t)256 << 10)) { block(dst, dpitch, src, spitch, row_bytes, 0, total); return; }
+        std::lock_guard<std::mutex> serial(serial_);         // one job at a time (contexts of several lanes share the pool)
+        Job j;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            job_ = {dst, src, dpitch, spitch, row_bytes, rows, total};
-            next_.store(0, std::memory_order_relaxed);
-            pending_ = nthreads_;
-            generation_++;
+            job_ = {dst, src, dpitch, spitch, row_bytes, total, ++generation_};
+            j = job_;
+            left_.store(total, std::memory_order_relaxed);
+            claim_.store((uint64_t)j.gen << 40, std::memory_order_release);
+            gen_atomic_.store(j.gen, std::memory_order_release);
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return pending_ == 0; });
+        work(j);
+        while (left_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();      // blocks other threads are still copying
     }
 
 private:
-    struct Job { char* dst; const char* src; size_t dpitch, spitch, row_bytes, rows, total; };
+    struct Job { char* dst; const char* src; size_t dpitch, spitch, row_bytes, total; uint64_t gen; };
     static constexpr size_t kBlock = (size_t)128 << 10;
 
     RowCopyPool()
     {
         int n = 3;                                            // + the calling thread
         if (const char* e = getenv("RAISR_HIP_COPY_THREADS")) { n = atoi(e) - 1; if (n < 0) n = 0; if (n > 15) n = 15; }
+        if (const char* e = getenv("RAISR_HIP_COPY_SPIN")) { spin_iters_ = atoi(e); if (spin_iters_ < 0) spin_iters_ = 0; }
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && (unsigned)n + 1 > hw) n = (int)hw - 1;
         for (int i = 0; i < n; i++) {
             try { std::thread(&RowCopyPool::loop, this).detach(); nthreads_++; } catch (...) { break; }
         }
     }
-    // byte range [from, to) of the job's payload (row-major over rows x row_bytes)
-    static void block(char* dst, size_t dpitch, const char* src, size_t spitch, size_t row_bytes, size_t rows, size_t from, size_t to)
+    // byte range [from, to) of the payload (row-major over rows x row_bytes)
+    static void block(char* dst, size_t dpitch, const char* src, size_t spitch, size_t row_bytes, size_t from, size_t to)
     {
-        (void)rows;
         while (from < to) {
             const size_t r = from / row_bytes, x = from % row_bytes;
             size_t n = row_bytes - x;
@@ -70,36 +77,49 @@ private:
             from += n;
         }
     }
-    void work()
+    void work(const Job& j)
     {
-        const Job j = job_;
         for (;;) {
-            const size_t from = next_.fetch_add(kBlock, std::memory_order_relaxed);
-            if (from >= j.total) break;
-            block(j.dst, j.dpitch, j.src, j.spitch, j.row_bytes, j.rows, from, from + kBlock < j.total ? from + kBlock : j.total);
+            uint64_t cur = claim_.load(std::memory_order_acquire);
+            size_t from;
+            for (;;) {
+                if ((cur >> 40) != (j.gen & 0xFFFFFFu)) return;           // a later job owns the word: nothing of this one is left
+                from = (size_t)(cur & (((uint64_t)1 << 40) - 1));
+                if (from >= j.total) return;
+                if (claim_.compare_exchange_weak(cur, cur + kBlock, std::memory_order_acq_rel)) break;
+            }
+            const size_t to = from + kBlock < j.total ? from + kBlock : j.total;
+            block(j.dst, j.dpitch, j.src, j.spitch, j.row_bytes, from, to);
+            left_.fetch_sub(to - from, std::memory_order_acq_rel);
         }
     }
     void loop()
     {
-        unsigned seen = 0;
+        uint64_t seen = 0;
         for (;;) {
+            bool have = false;
+            for (int spin = 0; spin < spin_iters_ && !have; spin++) {
+                if (gen_atomic_.load(std::memory_order_acquire) != seen) have = true;
+                else __builtin_ia32_pause();
+            }
+            Job j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return generation_ != seen; });
+                if (!have) cv_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
+                j = job_;
             }
-            work();
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--pending_ == 0) done_.notify_all();
+            work(j);
         }
     }
 
     std::mutex serial_, mu_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     Job job_{};
-    std::atomic<size_t> next_{0};
-    unsigned generation_ = 0;
-    int pending_ = 0;
+    uint64_t generation_ = 0;
+    std::atomic<uint64_t> gen_atomic_{0}, claim_{0};
+    std::atomic<size_t> left_{0};
+    int spin_iters_ = 20000;                                 // ~ 100-200 us of polling after a job (RAISR_HIP_COPY_SPIN=0: sleep at once)
     int nthreads_ = 0;
 };
 
