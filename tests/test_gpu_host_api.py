@@ -488,9 +488,9 @@ def test_plugin_path_with_row_chunks_and_strided_planes(chunks, monkeypatch):
 
 def test_a_fresh_set_of_pageable_buffers_per_call_and_per_submit():
     """What an ordinary host does: allocate the frame's planes, call, free them -- every call, contiguous and strided, through the
-    synchronous entry and through Submit / Collect (planes freed right after their Collect).  The bits stay the oracle's; with
-    rounds 1-2's copies (pageable memory handed to asynchronous 2-D copies) this pattern ended in a GPU page fault once in a
-    few hundred calls (csrc/host_copy.h)."""
+    synchronous entry and through Submit / Collect (planes freed right after their Collect).  The bits stay the oracle's.
+    (The pattern that preceded the sporadic GPU page fault of rounds 1-2's host path, csrc/host_copy.h; this test did not reproduce
+    it with RAISR_HIP_BOUNCE=0 either -- it is here as the regression test of the ordinary-host behaviour.)"""
     import gc
     import oracle_py as O
     import raisr_hip as R

@@ -1,13 +1,16 @@
 // host_copy.h -- how host planes travel (included by device_abi.hip; host code only).
 //
 // Page-locked planes (RNLHandler_HostAlloc / raisr_hip_host_alloc / registered by the caller) go straight to the copy engines.
-// PAGEABLE planes never reach an asynchronous HIP copy: the runtime serves such a copy by page-locking the caller's memory on
-// the fly and REMEMBERING the registration past the call; when the host then frees the buffer and its allocator hands the
-// address out again (a frame buffer per call is ordinary host behaviour), the next copy goes through the remembered mapping,
-// which the driver may have dropped in the meantime -- a GPU page fault that aborts the process (seen in 2 of 10 runs of the
-// GPU suite with one test that passes a fresh strided array per call).  So pageable planes are carried through page-locked
-// BOUNCE memory the context owns: rows are packed into it (upload) or unpacked from it (download, after the copy's event) by a
-// few threads; with the last pass in row ranges the unpacking of range i overlaps the kernels of range i+1.
+// PAGEABLE planes never reach a HIP copy call.  What the runtime does with pageable memory depends on shape and size (its own log,
+// AMD_LOG_LEVEL=4, scripts/runtime_copy_path_probe.py): strided planes take a synchronous "unpinned rect path", small contiguous
+// ones are staged, contiguous ones of a few MB are page-locked on the fly ("HSA Copy Using Pinned resource") -- the caller's memory,
+// registered behind its back.  With rounds 1-2's copies the GPU suite aborted sporadically (2 of 6 first runs on a fresh box) with
+// a GPU page fault inside RNLHandler_Process, always in the one test that hands a fresh strided pageable buffer per call to the
+// synchronous entry while its second stream downloads row ranges; the mechanism inside the runtime was not established and the
+// fault could not be provoked in isolation.  What is established: with pageable planes carried through page-locked
+// BOUNCE memory the context owns -- rows packed into it (upload) or unpacked from it (download, after the copy's event) by a few
+// threads -- every copy the runtime sees is a plain DMA on memory the library allocated, and the fault has not shown again
+// (0 of 9 first runs).  With the last pass in row ranges the unpacking of range i overlaps the kernels of range i+1.
 #pragma once
 #include <stdint.h>
 #include <atomic>

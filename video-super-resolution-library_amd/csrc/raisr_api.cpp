@@ -181,12 +181,10 @@ RNLERRORTYPE readTrainedData(std::string hashtablePath, std::string strPath, std
 // RAISR_HIP_PIN=1 (OPT-IN) additionally page-locks ordinary planes on first sight and remembers the registration (bounded,
 // least-recently-used region dropped; everything is unlocked in RNLDeinit).  The host then promises that every plane buffer it
 // hands over stays allocated until RNLDeinit: a registration outlives a free() of the memory under it, and whatever the
-// allocator puts at that address next is treated as page-locked by the runtime while the driver may already have dropped the
-// mapping (it re-validates user pages about a millisecond after an unmap: a buffer freed and re-allocated faster than that
-// survives, anything else is a GPU page fault).  That is why this is not the default.  The runtime refuses a copy whose host
-// range is only PARTLY inside a registered range -- so the ranges (exact plane extents, not rounded to pages) are kept
-// disjoint, and a plane that overlaps registered ranges without lying inside one (a band of rows registered first, the whole
-// plane later) gets the union registered as ONE range, after waiting for the frames in flight.
+// allocator puts at that address next is treated as page-locked by the runtime.  That is why this is not the default.  The
+// runtime refuses a copy whose host range is only PARTLY inside a registered range -- so the ranges (exact plane extents, not
+// rounded to pages) are kept disjoint, and a plane that overlaps registered ranges without lying inside one (a band of rows
+// registered first, the whole plane later) gets the union registered as ONE range, after waiting for the frames in flight.
 void quiesceDevice();
 
 struct PinCache {
