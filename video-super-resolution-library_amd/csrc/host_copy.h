@@ -23,8 +23,8 @@
 // One job at a time; its payload is cut into 128 KB blocks that the workers AND the caller claim from one atomic word
 // (job number << 40 | next byte offset), so a worker that wakes up late finds nothing to claim and cannot touch a later job with
 // an old descriptor; the caller returns when every claimed block has been copied (bytes-left counter), not when every worker
-// has checked in.  Workers poll for ~100 us after a job before they sleep on the condition variable: the copies of a frame come
-// in bursts, and a wake-up costs about as much as copying a chroma plane.
+// has checked in, so a sleeping worker costs nothing but its share of the copy.  (Letting the workers poll between the copies of
+// a frame was measured and does not pay: RAISR_HIP_COPY_SPIN.)
 class RowCopyPool {
 public:
     static RowCopyPool& get()
@@ -122,7 +122,7 @@ private:
     uint64_t generation_ = 0;
     std::atomic<uint64_t> gen_atomic_{0}, claim_{0};
     std::atomic<size_t> left_{0};
-    int spin_iters_ = 20000;                                 // ~ 100-200 us of polling after a job (RAISR_HIP_COPY_SPIN=0: sleep at once)
+    int spin_iters_ = 0;                                     // RAISR_HIP_COPY_SPIN=n: poll n times for the next job before sleeping (measured: no gain, 3 busy cores)
     int nthreads_ = 0;
 };
 
