@@ -14,7 +14,10 @@ REF = "/root/reference/ffmpeg/vf_raisr.c"
 def test_build_system_patch_mentions_every_touch_point():
     s = open(os.path.join(ROOT, "ffmpeg", "0001-ffmpeg-raisr-hip-filter.patch")).read()
     for needle in ("--enable-libraisr", "raisr_filter_deps=\"libraisr\"", "-lraisr_hip -lamdhip64 -lstdc++", "RNLHandler_Init",
-                   "OBJS-$(CONFIG_RAISR_FILTER)", "extern const AVFilter ff_vf_raisr;"):
+                   "OBJS-$(CONFIG_RAISR_FILTER)", "extern const AVFilter ff_vf_raisr;",
+                   # the hardware-frames filter (ffmpeg/vf_raisr_hipframes.c), as the reference patch wires raisr_opencl
+                   'raisr_hip_filter_deps="libraisr vaapi libdrm"', "OBJS-$(CONFIG_RAISR_HIP_FILTER)              += vf_raisr_hipframes.o",
+                   "extern const AVFilter ff_vf_raisr_hip;"):
         assert needle in s, needle
     assert "libipp" not in s                        # the CPU library's IPP dependency is gone
 
@@ -65,3 +68,38 @@ def test_hardware_frames_filter_compiles_against_our_headers():
     for needle in ("hipImportExternalMemory", "hipExternalMemoryGetMappedBuffer", "HIPExternal", "RAISR_HIP_INTERLEAVED2",
                    "RNLHandler_SetOpenCLContext(ctx->stream, NULL, 0, ctx->device)", "DRM_FORMAT_MOD_LINEAR_", "FF_FILTER_FLAG_HWFRAME_AWARE"):
         assert needle in text, needle
+
+
+def test_build_system_patch_hunks_are_well_formed():
+    """Every hunk of the n6.0 build-system patch has the line counts its header announces, and the new-file offsets of a file's
+    hunks grow by exactly the lines the earlier hunks added (the patch cannot be applied here: no FFmpeg tree in the image)."""
+    import re
+    s = open(os.path.join(ROOT, "ffmpeg", "0001-ffmpeg-raisr-hip-filter.patch")).read()
+    body = s[s.index("diff --git"):]
+    added_total = 0
+    for filediff in body.split("diff --git")[1:]:
+        lines = filediff.split("\n")
+        shift = 0
+        i = 0
+        while i < len(lines):
+            m = re.match(r"@@ -(\d+),(\d+) \+(\d+),(\d+) @@", lines[i])
+            if not m:
+                i += 1
+                continue
+            a, b, c, d = map(int, m.groups())
+            assert c == a + shift, (lines[i], shift)
+            i += 1
+            ctx = add = rem = 0
+            while i < len(lines) and not lines[i].startswith(("@@", "diff --git")) and (ctx + rem < b or ctx + add < d):
+                if lines[i].startswith("+"):
+                    add += 1
+                elif lines[i].startswith("-"):
+                    rem += 1
+                else:
+                    ctx += 1
+                i += 1
+            assert ctx + rem == b and ctx + add == d, (m.group(0), ctx, add, rem)
+            shift += add - rem
+            added_total += add
+    stat = re.search(r"(\d+) files changed, (\d+) insertions", s)
+    assert stat and int(stat.group(2)) == added_total, (stat.group(0) if stat else None, added_total)
