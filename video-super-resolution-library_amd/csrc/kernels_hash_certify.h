@@ -229,9 +229,14 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* s
     tensor_acN<4, GT>(S, sG, reinterpret_cast<typename FVec<4>::type*>(sV), ta, tb, td, tid);
 }
 
+// In-tile worklist of k_hashfilter_ac: more uncertain pixels than this and the whole tile takes the all-exact routine -- it then
+// pays the approximate AND the exact work.  160 entries: measured 48 / 96 / 160 / 256 / 320 (scripts/r03_call28.sh, r03_call29.sh);
+// with 48, tiles of AVX2-flavour frames (twice the uncertified share: their table error is 6.5e-4) overflowed often enough that C1
+// ran 13 % (random frames: 21 %) slower than with 160, C2 / C3 / C5 1-2 %; beyond 160 nothing changes.
+constexpr unsigned kListMax = 160;
+
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
-constexpr unsigned kListMax = 48;             // in-tile worklist of k_hashfilter_ac: more uncertain pixels -> the whole tile takes the exact routine
 template <int LW, typename GT, int RPW = 4>
 __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, typename FVec<RPW>::type* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
