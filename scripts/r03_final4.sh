@@ -4,7 +4,7 @@
 # BASELINE configuration, smoke.
 TAG=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/${TAG}_final2; mkdir -p $O
+O=gpurun_out/${TAG}_final4; mkdir -p $O
 gcc -shared -fPIC -o /tmp/abort_trace.so scripts/abort_trace.c
 ( time LD_PRELOAD=/tmp/abort_trace.so timeout 1800 python -m pytest tests/ -x -q -m gpu ) > $O/gpu_suite.log 2>&1; tail -4 $O/gpu_suite.log
 ( time timeout 900 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; tail -4 $O/bench.err
