@@ -296,19 +296,29 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
             float wl[11];
 #pragma unroll
             for (int i = 0; i < 11; i++) wl[i] = P.gauss_dev[min(l, 10) * 12 + i];
+            // two phases: the tensors with 16 lanes per entry (rounds over the waves), parked behind the table in sV's space; then
+            // the hash with ONE LANE PER ENTRY -- the hash is ~200 instructions whether 4 or 64 lanes of a wave are active, and
+            // in a one-phase loop every wave issues it for its own 4 entries per round (measured, scripts/r03_call31.sh: C1 +9 %,
+            // C2 / C3 / C5 +1.5 %)
+            float4* sAbd = reinterpret_cast<float4*>(const_cast<uint2*>(sTab) + 128);
             for (unsigned rd = (unsigned)w; 4u * rd < n; rd += 4u) {
                 const unsigned e = 4u * rd + (unsigned)g;
                 const unsigned ent = sList[min(e, n - 1u)];
                 const int prow = (ent >> 6) & 15, pcol = ent & 63;
                 float a, b, d;
                 exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
-                if (l == 0 && e < n) {
-                    unsigned hA, hB;
-                    flavour_hash(P, sTab, a, b, d, c0 + pcol, hA, hB);
-                    if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
-                    sH[prow * TW + pcol] = (uint8_t)hA;
-                    sH2[prow * TW + pcol] = (uint8_t)hB;
-                }
+                if (l == 0 && e < n) sAbd[e] = float4{a, b, d, 0.0f};
+            }
+            __syncthreads();
+            if (tid < n) {
+                const unsigned ent = sList[tid];
+                const int prow = (ent >> 6) & 15, pcol = ent & 63;
+                const float4 t = sAbd[tid];
+                unsigned hA, hB;
+                flavour_hash(P, sTab, t.x, t.y, t.z, c0 + pcol, hA, hB);
+                if ((ent & 0x8000u) && (sH[prow * TW + pcol] != (uint8_t)hA || (hB != 0xFFu && sH2[prow * TW + pcol] != (uint8_t)hB))) bad++;
+                sH[prow * TW + pcol] = (uint8_t)hA;
+                sH2[prow * TW + pcol] = (uint8_t)hB;
             }
         }
     } else {
