@@ -13,7 +13,8 @@ torch.distributed.run, RCCL backend, one rank per device) and refuses to print a
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     -- dominant kernel: algorithmic bytes per launch / average launch duration, measured with HIP
-                  events on the kernel's own stream over the timed region (+ the fp32-VALU figure that binds)
+                  events on the kernel's own stream over the timed region (+ the figures that bind: `l1` = the vector-L1
+                  delivery floor of the filter stage over the isolated launch, `valu` = algorithmic FLOPs over the fp32-VALU peak)
   cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample
 and, at N = 1 (outside the timed region of `value`, never mixed into it):
   c3_2pass     -- the same loop for BASELINE.json configs[2] (2-pass: north_star's target configuration)
@@ -48,6 +49,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md
 VALU_FP32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md "Peak FP32 (vector)": 4 SIMD-32 per CU, all-FMA.
+L1_PROBE_B_PER_CLK_CU = 55.0                                 # scripts/l1_width_probe.hip: 54-62 B/clk/CU delivered to the lanes (dword / dwordx4 loads)
+N_CUS = 256
+CLOCK_HZ = 2.4e9
 VALU_FP16_PEAK_TFLOPS = 314.6                                # packed binary16 (v_pk_fma_f16): two lanes per fp32 lane, same issue rate
 # (scripts/valu_rate_probe.hip sustains 911 G wave-inst/s = 116.6 TFLOP/s of v_fma_f32 on this power-limited part.)
 # SURVEY.md s8d per-filtered-pixel ALGORITHMIC FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add,
@@ -347,8 +351,8 @@ def roofline_of(wl, kern, iso, lanes_n):
                 "isolated_launch_ms": round(iso[dom], 4) if dom in iso else None,
                 "algorithmic_bytes_per_launch": wl.algo_bytes // launches_per_frame,
                 "lanes_overlapped": lanes_n,
-                "note": "path is fp32-VALU / LDS / vector-L1 bound (~1.3 kFLOP per output pixel vs 1.25 compulsory bytes); the HBM "
-                        "fraction is reported as required, roofline.valu is the binding figure (DESIGN.md s5)"}
+                "note": "path is vector-L1 / fp32-VALU / LDS bound (~1.3 kFLOP and 512 B of L1-delivered coefficients per output pixel vs 1.25 "
+                        "compulsory bytes); the HBM fraction is reported as required, roofline.l1 and roofline.valu are the binding figures (DESIGN.md s5)"}
     if dom in iso:
         roofline["frac_isolated"] = round(wl.algo_bytes / launches_per_frame / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
     # the binding roofline: algorithmic FLOPs of the hash+filter stages over their isolated durations
@@ -369,6 +373,17 @@ def roofline_of(wl, kern, iso, lanes_n):
         if not fp16:                                 # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
             roofline["valu"].update({"sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)})
         roofline["binding"] = "f16-valu" if fp16 else "fp32-valu"
+        # What the fp32 kernel is measured to be bound by (profiles/r03_l1_width_probe.md, r03_C2_texture_path_counters.md):
+        # the filter stage fetches 128 fp32 coefficients per pixel through the vector L1, which delivers ~55 B/clk/CU to the lanes for
+        # this access pattern whatever the load width.  The floor of ANY kernel that sources its coefficients there:
+        bytes_px = 256 if fp16 else 512
+        floor_ms = zone * bytes_px / (L1_PROBE_B_PER_CLK_CU * N_CUS * CLOCK_HZ) * 1e3
+        roofline["l1"] = {"coefficient_bytes_per_pixel": bytes_px, "probe_rate_B_per_clk_per_cu": L1_PROBE_B_PER_CLK_CU,
+                          "floor_ms": round(floor_ms, 4), "isolated_ms": round(iso[dom], 4) if dom in iso else None,
+                          "frac": round(floor_ms / iso[dom], 4) if dom in iso else None,
+                          "what": "vector-L1 delivery floor of the filter stage / isolated launch of the dominant kernel"}
+        if not fp16:
+            roofline["binding"] = "vector-l1 (filter stage), fp32-valu second"
     return roofline
 
 
