@@ -9,10 +9,22 @@ w, h = 1920, 1080
 fold = os.path.join(ROOT, "filters_2x", "filters_highres")
 n = int(os.environ.get("N", "400"))
 pinned = int(os.environ.get("PIN", "0"))
-ys = [synth.natural_y(w, h, 8, seed=i) for i in range(4)]
-u = synth.chroma(w // 2, h // 2, 8); v = u.copy()
-oy = np.zeros((2 * h, 2 * w), np.uint8); ou = np.zeros((h, w), np.uint8); ov = np.zeros((h, w), np.uint8)
-if pinned:
+hostalloc = int(os.environ.get("HOSTALLOC", "0"))          # 1: every plane from RNLHandler_HostAlloc
+keep = []
+
+
+def plane(a):
+    if not hostalloc:
+        return a
+    keep.append(R.HostPlane(a.shape, a.dtype))
+    keep[-1].array[...] = a
+    return keep[-1].array
+
+
+ys = [plane(synth.natural_y(w, h, 8, seed=i)) for i in range(4)]
+u = plane(synth.chroma(w // 2, h // 2, 8)); v = plane(u.copy())
+oy = plane(np.zeros((2 * h, 2 * w), np.uint8)); ou = plane(np.zeros((h, w), np.uint8)); ov = plane(np.zeros((h, w), np.uint8))
+if pinned and not hostalloc:
     for a in ys + [u, v, oy, ou, ov]:
         assert R.lib().raisr_hip_host_register(a.ctypes.data, a.nbytes) == 0
 R.RNLHandler_SetOpenCLContext(0, 0)
@@ -23,4 +35,4 @@ t0 = time.perf_counter()
 for i in range(n): R.RNLHandler_Process((ys[i % 4], u, v), (oy, ou, ov))
 dt = time.perf_counter() - t0
 R.RNLHandler_Deinit()
-print(f"pinned={pinned} bands={os.environ.get('RAISR_HIP_BANDS', '-')}: {n / dt:.0f} fps ({dt / n * 1e6:.0f} us/frame)", file=sys.stderr)
+print(f"hostalloc={hostalloc} pinned={pinned} bands={os.environ.get('RAISR_HIP_BANDS', '-')}: {n / dt:.0f} fps ({dt / n * 1e6:.0f} us/frame)", file=sys.stderr)
