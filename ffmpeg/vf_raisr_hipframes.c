@@ -22,6 +22,7 @@
  * it calls are exercised on the GPU by tests/test_gpu_host_api.py::test_hipexternal_device_planes_against_the_oracle.
  */
 #include <unistd.h>
+#include <sys/stat.h>
 #include <hip/hip_runtime_api.h>
 
 #include "raisr/RaisrHandler.h"
@@ -38,7 +39,11 @@
 #define DRM_FORMAT_MOD_LINEAR_ 0ULL
 
 typedef struct ImportedObject {
-    int fd;                                /* dma-buf as exported by the mapping (the key; dup()ed: ours to close) */
+    /* Identity of the dma-buf.  NOT the descriptor number: av_hwframe_map() exports fresh descriptors per call and
+     * av_frame_free() of the mapping closes them, so the kernel hands the same small numbers to different surfaces from the
+     * second frame on.  Every dma-buf has its own inode on the dmabuf pseudo filesystem for as long as the buffer lives. */
+    dev_t st_dev;
+    ino_t st_ino;
     size_t size;
     hipExternalMemory_t mem;
     void *base;                            /* device pointer of the whole object */
@@ -71,9 +76,14 @@ static int import_object(AVFilterContext *avctx, int fd, size_t size, void **bas
     hipExternalMemoryHandleDesc hd = { 0 };
     hipExternalMemoryBufferDesc bd = { 0 };
     ImportedObject *io;
+    struct stat st;
 
+    if (fstat(fd, &st) < 0) {
+        av_log(avctx, AV_LOG_ERROR, "fstat of dma-buf %d failed\n", fd);
+        return AVERROR(EINVAL);
+    }
     for (int i = 0; i < ctx->nb_imports; i++)
-        if (ctx->imports[i].fd == fd && ctx->imports[i].size == size) {
+        if (ctx->imports[i].st_ino == st.st_ino && ctx->imports[i].st_dev == st.st_dev && ctx->imports[i].size == size) {
             *base = ctx->imports[i].base;
             return 0;
         }
@@ -97,7 +107,8 @@ static int import_object(AVFilterContext *avctx, int fd, size_t size, void **bas
         av_log(avctx, AV_LOG_ERROR, "hipExternalMemoryGetMappedBuffer failed\n");
         return AVERROR(ENOMEM);
     }
-    io->fd = fd;
+    io->st_dev = st.st_dev;
+    io->st_ino = st.st_ino;
     io->size = size;
     ctx->nb_imports++;
     *base = io->base;

@@ -36,7 +36,8 @@ def test_api_names_in_the_documents_are_declared():
 def test_environment_variables_in_the_documents_are_read_by_the_code():
     srcs = _read(glob.glob(os.path.join(ROOT, "video-super-resolution-library_amd", "csrc", "*")) +
                  glob.glob(os.path.join(ROOT, "video-super-resolution-library_amd", "*.py")) + [os.path.join(ROOT, "bench.py")] +
-                 glob.glob(os.path.join(ROOT, "scripts", "*")) + glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "include", "raisr", "*.h")))
+                 [f for f in glob.glob(os.path.join(ROOT, "scripts", "*")) + glob.glob(os.path.join(ROOT, "scripts", "sessions", "*")) if os.path.isfile(f)] +
+                 glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "include", "raisr", "*.h")))
     missing = {}
     for doc in DOCS:
         text = open(os.path.join(ROOT, doc)).read()
@@ -71,7 +72,7 @@ def test_every_script_is_listed_in_scripts_readme():
     ranges = [(p, int(a), int(b)) for p, a, b in re.findall(r"`(\w+?)(\d+)\.sh` … `\w+?(\d+)\.sh`", text)]      # `r03_call1.sh` … `r03_call16.sh`
     missing = []
     for fn in sorted(os.listdir(os.path.join(ROOT, "scripts"))):
-        if fn == "README.md" or fn in expanded:
+        if fn == "README.md" or fn in expanded or fn == "sessions":      # sessions/: the GPU sessions' command lists, described as a group
             continue
         m = re.match(r"(\w+?)(\d+)\.sh$", fn)
         if m and any(p == m.group(1) and a <= int(m.group(2)) <= b for p, a, b in ranges):

@@ -1,0 +1,107 @@
+"""CPU: the lane program of the symmetric filter stage (csrc/kernels_filter.h, filter_phase<.., SYM>) replayed in numpy
+against the reference's plain 16-lane chains (Raisr_AVX512.cpp:134-149, sumitup_ps_512 :37-44).
+
+For a palindromic bank row (f[k] == f[120 - k]) each lane loads four coefficients instead of eight, runs taps ch = 0..3 of its
+own chain, hands the accumulator to lane (8 - l) & 15 and continues there with the partner chain's taps ch = 4..7 on the same
+four registers.  The claim the kernel relies on: all 16 lanes end with the reference's bits, signed zeros included.
+Also: which of the shipped banks qualify (the facts DESIGN.md quotes)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+
+
+def fma(a, b, c):
+    # a*b is exact in binary64 for binary32 operands; the sum is rounded to binary64 then binary32.  Double rounding could differ
+    # from a true fma in rare ties, but both sides of the comparison use this same function on the same operand triples.
+    return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def tree(a):
+    r8 = [f32(a[i] + a[(i + 8) % 16]) for i in range(16)]
+    r4 = [f32(r8[i] + r8[(i + 4) % 16]) for i in range(16)]
+    r2 = [f32(r4[i] + r4[(i + 2) % 16]) for i in range(16)]
+    return [f32(r2[i] + r2[(i + 1) % 16]) for i in range(16)]
+
+
+def reference_lanes(p, f):
+    acc = [f32(p[l] * f[l]) for l in range(16)]
+    for ch in range(1, 8):
+        acc = [fma(p[16 * ch + l], f[16 * ch + l], acc[l]) for l in range(16)]
+    return tree(acc)
+
+
+def symmetric_lanes(p, f):
+    cf = [[f[16 * c + l] for c in range(4)] for l in range(16)]          # the only coefficients a lane loads
+    a = [f32(p[l] * cf[l][0]) for l in range(16)]
+    for c in range(1, 4):
+        a = [fma(p[16 * c + l], cf[l][c], a[l]) for l in range(16)]
+    a = [a[(8 - q) % 16] for q in range(16)]                               # partner_xchg
+    for q in range(16):
+        l2 = (8 - q) % 16
+        if q <= 8:
+            taps = [16 * (4 + j) + l2 for j in range(4)]
+            g = [cf[q][3], cf[q][2], cf[q][1], cf[q][0]]
+        else:                                                              # padding step first, then taps ch = 4, 5, 6
+            taps = [None] + [16 * (3 + j) + l2 for j in range(1, 4)]
+            g = [f32(0), cf[q][2], cf[q][1], cf[q][0]]
+        for j in range(4):
+            x = p[0] if taps[j] is None else p[taps[j]]
+            a[q] = fma(x, g[j], a[q])
+    return tree(a)
+
+
+def palindrome_row(rng, negatives=False):
+    h = (rng.standard_normal(61) * 0.1).astype(f32)
+    if negatives:
+        h = -np.abs(h)
+    f = np.zeros(128, f32)
+    f[:61] = h
+    f[60:121] = h[::-1]
+    return f
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_symmetric_lane_program_gives_the_reference_bits(seed):
+    rng = np.random.default_rng(seed)
+    for trial in range(400):
+        f = palindrome_row(rng, negatives=trial % 7 == 0)
+        p = np.zeros(128, f32)
+        p[:121] = rng.integers(0, 1024, 121).astype(f32)
+        if trial % 5 == 0:
+            p[:121] *= rng.random(121) < 0.1                               # mostly zero patches: signed-zero chains
+        if trial % 11 == 0:
+            p[:] = 0
+        want, got = reference_lanes(p, f), symmetric_lanes(p, f)
+        assert [x.view(np.uint32) for x in want] == [x.view(np.uint32) for x in got], trial
+
+
+def test_partner_map_is_the_two_dpp_moves():
+    # row_mirror then row_ror:9 (lane p reads lane (p - 9) & 15): result[p] = v[15 - ((p - 9) & 15)] = v[(8 - p) & 15]
+    v = list(range(16))
+    t = [v[15 - p] for p in range(16)]
+    r = [t[(p - 9) % 16] for p in range(16)]
+    assert r == [(8 - p) % 16 for p in range(16)]
+
+
+def _bank(path):
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"fp32"
+    n = np.frombuffer(raw[4:16], np.uint32)
+    return np.frombuffer(raw[16:], np.uint32).reshape(int(n[0]) * int(n[1]), 121)
+
+
+def test_which_shipped_banks_are_palindromic():
+    counts = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "filters_*", "*", "filterbin_*"))):
+        a = _bank(path)
+        counts[os.path.relpath(path, ROOT)] = int((a != a[:, ::-1]).any(axis=1).sum())
+    # the headline model: 2 of 864 rows are not palindromes (two coefficient pairs off by one ulp each)
+    assert counts["filters_2x/filters_highres/filterbin_2_8"] == 2
+    assert counts["filters_2x/filters_highres/filterbin_2_10_2"] == 2
+    assert counts["filters_2x/filters_highres/filterbin_2_10"] == 50
+    assert counts["filters_2x/filters_lowres/filterbin_2_8"] > 400      # not symmetric: the eight-load stage runs

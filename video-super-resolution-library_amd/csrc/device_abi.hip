@@ -102,6 +102,9 @@ struct ModelDev {
     int zero_bucket[2] = {0, 0};           // bucket of the all-zero tensor, AVX-512 / AVX2 flavour (from the device hash code)
     _Float16* bank_mfma = nullptr;         // fast mode: binary16 B panels of k_filter_mfma, built on first use
     bool bank_mfma_valid = false;
+    // symmetric filter stage (kernels_filter.h, filter_phase<.., SYM>): which bank rows are NOT palindromes
+    uint32_t* d_asym = nullptr;            // [32] bitmap over bucket * pixel_types + type (allocated with the first model)
+    int asym_rows = -1;                    // number of set bits; -1 = not scanned (the symmetric kernel is never chosen then)
 };
 
 struct KernelTimer {
@@ -206,6 +209,8 @@ struct raisr_hip_ctx {
     hipEvent_t ev_kern = nullptr;
     bool ev_kern_valid = false;
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
+    int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     int fast = 0;                              // NON-bit-exact fast mode (raisr_hip_set_fast / RAISR_HIP_FAST): 1 = exact buckets, filter stage on the matrix cores; 2 = also keeps the approximate tensor's bucket where it is not certified
@@ -329,6 +334,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.lut_legacy = c->d_lut;
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
     P.gauss_dev = c->d_gauss;
+    P.asym = (m.asym_rows > 0) ? m.d_asym : nullptr;
     return P;
 }
 
@@ -351,6 +357,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 4 * R - 1) / (4 * R));
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
+        const int asym_rows = c->model[pass].asym_rows;
+        const bool sym = c->sym && asym_rows >= 0 && asym_rows <= c->sym_max_rows;   // symmetric filter stage of k_hashfilter_ac
         if (c->fast || (c->fused && c->certify && c->split)) {
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
@@ -416,7 +424,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 const int b1 = i == nchunks - 1 ? Tb : t1;
                 P.tile_y0 = t0;
                 timer_begin(c, "k_hashfilter_ac", s, slot);
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 timer_end(c, s, slot);
                 timer_begin(c, "k_blend", s, slot);
                 hipLaunchKernelGGL((k_blend<TOut>), dim3((W + 63) / 64, (unsigned)(b1 - t0)), dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
@@ -436,7 +445,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             if (part == 1)
                 hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             else if (part == 2)
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                { if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                  else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]); }
             else
 #endif
 #ifdef RAISR_EXP_PERSIST
@@ -459,7 +469,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                     hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 2>), dim3(gf.x, (unsigned)((H - 2 * kMargin + 7) / 8)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 else
 #endif
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
@@ -648,6 +659,8 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
+    if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
@@ -723,6 +736,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     free_scratch(c);
     for (int i = 0; i < 2; i++) if (c->model[i].blob) (void)hipFree(c->model[i].blob);
     for (int i = 0; i < 2; i++) if (c->model[i].bank_mfma) (void)hipFree(c->model[i].bank_mfma);
+    for (int i = 0; i < 2; i++) if (c->model[i].d_asym) (void)hipFree(c->model[i].d_asym);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
@@ -781,6 +795,36 @@ int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, 
     return RAISR_HIP_OK;
 }
 
+// Which rows of the fp32 bank are palindromes (f[k] == f[120 - k], compared as bit patterns)?  Decides whether the symmetric
+// filter stage may run for this model and lists the rows whose pixels it has to redo with all eight coefficient loads.
+// `host_bank` = the blob's fp32 bank [rows][128] on the host, or null: then it is read back from the device blob.
+static int scan_bank_symmetry(raisr_hip_ctx* c, int pass_index, const float* host_bank)
+{
+    ModelDev& m = c->model[pass_index];
+    m.asym_rows = -1;
+    const int rows = m.h.hashkeys * m.h.pixel_types;
+    std::vector<float> back;
+    if (!host_bank) {
+        back.resize((size_t)rows * kTapsPad);
+        HIP_TRY(hipMemcpy(back.data(), (const char*)m.blob + kBlobHeader, blob_f32_bytes(rows), hipMemcpyDeviceToHost));
+        host_bank = back.data();
+    }
+    uint32_t bits[32] = {0};
+    int n = 0;
+    for (int r = 0; r < rows && r < 1024; r++) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(host_bank + (size_t)r * kTapsPad);
+        bool pal = true;
+        for (int k = 0; k < 60 && pal; k++) pal = f[k] == f[120 - k];
+        for (int k = kTaps; k < kTapsPad && pal; k++) pal = f[k] == 0u;            // the padding must be +0 (it is: pack_model_blob)
+        if (!pal) { bits[r >> 5] |= 1u << (r & 31); n++; }
+    }
+    if (!m.d_asym) { if (hipMalloc((void**)&m.d_asym, sizeof bits) != hipSuccess) { m.d_asym = nullptr; return fail(RAISR_HIP_ENOMEM, "hipMalloc"); } }
+    HIP_TRY(hipMemcpy(m.d_asym, bits, sizeof bits, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    m.asym_rows = n;
+    return RAISR_HIP_OK;
+}
+
 // Bucket of the all-zero structure tensor (flat windows) in both hash flavours, from the device's exact hash code:
 // the certified hash stage looks it up instead of hashing (0, 0, 0) per pixel.
 static int compute_zero_buckets(raisr_hip_ctx* c, int pass_index)
@@ -821,6 +865,7 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     HIP_TRY(hipMemcpyAsync(m.blob, device_blob, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     m.bytes = bytes; m.h = h; m.valid = true; m.bank_mfma_valid = false;
+    if (int rc = scan_bank_symmetry(c, pass_index, nullptr)) return rc;
     return compute_zero_buckets(c, pass_index);
 }
 
@@ -870,6 +915,7 @@ int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int
     HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());           // frames run on non-blocking streams, which nothing orders after a null-stream copy
     m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true; m.bank_mfma_valid = false;
+    if (int rc = scan_bank_symmetry(c, pass_index, (const float*)(host.data() + kBlobHeader))) return rc;
     return compute_zero_buckets(c, pass_index);
 }
 

@@ -36,6 +36,8 @@ struct PassParams {
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
+    const uint32_t* asym;        // symmetric filter stage (filter_phase<.., SYM>): bitmap [32 words] of the (bucket * pixel_types + type) bank rows
+                                 // that are NOT palindromic (f[k] != f[120-k] somewhere), or null when every row is
     int tile_y0;                 // first tile row of this launch (k_hashfilter_ac / k_blend launched on a range of tile rows: the host
                                  // path pipelines the download of finished rows with the kernels of the next rows)
 };

@@ -31,9 +31,38 @@ __device__ __forceinline__ float tree16(float acc)
     return acc;
 }
 
+// Symmetric banks.  Most rows of the shipped high-resolution banks are palindromes, f[k] == f[120 - k] bit for bit (the
+// trained filters are point-symmetric; 862 of 864 rows of filters_2x/filters_highres/filterbin_2_8).  For such a row the
+// reference's zmm lane l (taps l, 16 + l, ..., 112 + l) and lane l' = (8 - l) & 15 need the SAME eight coefficients in opposite
+// order: f[16 ch + l] = f[120 - 16 ch - l] = f[16 (7 - ch) + (8 - l)] (l <= 8), = f[16 (6 - ch) + (24 - l)] (l >= 9, whose
+// eighth tap 112 + l is padding).  filter_phase<.., SYM> therefore loads only the four coefficients f[16 c + l], c = 0..3
+// (the first 256 B of the row: half the bytes through the vector L1, the resource that binds this stage), runs taps
+// ch = 0..3 of lane l's chain, hands the accumulator to the partner lane with two DPP moves (partner_xchg) and continues
+// there with taps ch = 4..7 of chain l' = (8 - l) & 15 on the coefficients that lane already holds, in reverse order.
+// Every chain still sees its eight fused multiply-adds in the reference's order; the 16 sums end up permuted by
+// l -> (8 - l) & 15, which maps the summation tree of sumitup_ps_512 onto itself (it flips tree levels only), so the
+// tree's result is the same bits.  For l >= 9 the chain's padding step (p = +0, f = +0: acc + (+0)) runs as the FIFTH step
+// instead of the eighth so that both lane classes use the registers (c3 | +0, c2, c1, c0) for steps 4..7; moving
+// "+ (+0)" inside the chain cannot change its value: it only turns -0 into +0, which the reference's final padding step
+// does anyway, and a chain that is -0 at any point consists of -0 products only.  (tests/test_sym_filter_model.py replays
+// this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes are listed in P.asym;
+// their pixels are redone with the full eight loads after the row's main loop.
+__device__ __forceinline__ float partner_xchg(float v)      // lane p of every row of 16 receives lane (8 - p) & 15
+{
+#ifdef RAISR_EXP_SYM_BPERM                                  // experiment: through the LDS crossbar instead of two VALU moves
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) | ((8u - lane) & 15u)) * 4u), __float_as_int(v)));
+#endif
+    // (every lane of a row has a source lane: `old` is never used, so it is the source itself and no register is zeroed for it)
+    const int x = __float_as_int(v);
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, true);                      // row_mirror: t[p] = v[15 - p]
+    t = __builtin_amdgcn_update_dpp(t, t, 0x129, 0xf, 0xf, true);                          // row_ror:9 : lane p reads lane (p - 9) & 15
+    return __int_as_float(t);
+}
+
 // filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
-template <int LW, int RPW = 4>
+template <int LW, int RPW = 4, bool SYM = false>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
                                              int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x)
 {
@@ -43,10 +72,15 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     int off[8];
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
-        const int k = 16 * ch + l;
+        int k = 16 * ch + l;
+        if (SYM && ch >= 4) {                                   // steps 4..7 run the partner's chain l2 on this lane
+            const int l2 = (8 - l) & 15;
+            k = l <= 8 ? 16 * ch + l2 : (ch == 4 ? kTaps : 16 * (ch - 1) + l2);   // l >= 9: padding step first, then taps ch = 4, 5, 6
+        }
         off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
         asm volatile("" : "+v"(off[ch]));                      // one register per tap: left alone, the compiler keeps row and column part apart (16 VGPRs)
     }
+    const unsigned maskA = (SYM && l >= 9) ? 0u : 0xFFFFFFFFu;   // SYM: step 4 multiplies by c3 (l <= 8) or by +0 (the padding step of l >= 9)
 
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
     const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -68,6 +102,31 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
+        // The plain 16-lane chains of one step with all eight loads (tail re-hash and, in the symmetric variant, the pixels of
+        // non-palindromic rows).  The symmetric variant has no registers for the plain tap offsets: it recomputes them here, behind
+        // an opaque lane index so that they are not hoisted into the main loop's live range.
+        auto plain_step = [&](int s, unsigned hb) -> float {
+            const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
+            float acc;
+            if (!SYM) {
+                acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+            } else {
+                int lq = l;
+                asm volatile("" : "+v"(lq));
+                const float* base = sL + prow * LW + g + 4 * s;
+                acc = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 8; ch++) {
+                    const int k = 16 * ch + lq;
+                    const float x = base[(k < kTaps) ? (k / 11) * LW + (k % 11) : 0];
+                    const float f = RAISR_BANK_F(voff + 64u * ch);
+                    acc = ch == 0 ? x * f : __builtin_fmaf(x, f, acc);
+                }
+            }
+            return tree16(acc);
+        };
         float keep = 0.0f;
         const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
         // The 16 steps (4 adjacent pixels each) go in four groups {j, j+4, j+8, j+12}: the lane that keeps step s is
@@ -86,9 +145,23 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
                 // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
                 // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
                 const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
-                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+                float acc;
+                if (!SYM) {
+                    acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                    for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                } else {
+                    const float q0 = RAISR_BANK_F(voff), q1 = RAISR_BANK_F(voff + 64u), q2 = RAISR_BANK_F(voff + 128u), q3 = RAISR_BANK_F(voff + 192u);
+                    acc = RAISR_LDS_F(tap[0], s) * q0;
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[2], s), q2, acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[3], s), q3, acc);
+                    acc = partner_xchg(acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), __uint_as_float(__float_as_uint(q3) & maskA), acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[5], s), q2, acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[6], s), q1, acc);
+                    acc = __builtin_fmaf(RAISR_LDS_F(tap[7], s), q0, acc);
+                }
                 acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
                 part[m] = acc + row_ror<0x124>(acc);           // r4[i] = r8[i] + r8[i+4]   (period 4 over the 16 lanes)
             }
@@ -103,16 +176,26 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             // lane (g,l) keeps pixel column 4l+g, i.e. step l: in group j those are the lanes with (l & 3) == j
             asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
         }
+        if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
+            const unsigned hrow = sH[prow * TW + lane];
+            const unsigned key = hrow * (unsigned)P.pixel_types + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
+            const bool af = hrow != 0xFFu && ((P.asym[key >> 5] >> (key & 31u)) & 1u);
+            const unsigned long long am = __ballot(af);
+            if (am) {
+#pragma unroll 1
+                for (int s = 0; s < 16; s++) {
+                    if (((am >> (4 * s)) & 0xFull) == 0) continue;
+                    const float v = plain_step(s, sH[prow * TW + 4 * s + g]);
+                    if (s == l && ((am >> (4 * s + g)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
+                }
+            }
+        }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
             for (int s = 0; s < 16; s++) {
                 const unsigned hB = sH2[prow * TW + 4 * s + g];
                 if (hB == 0xFFu) continue;
-                const unsigned voff = __umul24(hB, bank_stride) + row_lane_off;
-                float acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
-#pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
-                const float v = tree16(acc);
+                const float v = plain_step(s, hB);
                 if (s == l) {
                     if (v > P.lo && v < P.hi) keep = v;
                     else if (P.randomness) keep = RAISR_LDS_F(ctr, s);
@@ -203,7 +286,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
 // one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
-template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4>
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false>
 __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
                                                    uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
                                                    float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x)
@@ -259,7 +342,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
 #ifdef RAISR_EXP_PERSIST_PRIO
     __builtin_amdgcn_s_setprio(3);                           // experiment: filter-stage waves first (what oldest-first arbitration gives the non-persistent grid)
 #endif
-    if (PART != 1) filter_phase<LW, RPW>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
+    if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
 #ifdef RAISR_EXP_PERSIST_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -269,7 +352,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
 #ifndef RAISR_EXP_TILE8_WGS
 #define RAISR_EXP_TILE8_WGS 6
 #endif
-template <typename T, int PART = 0, int RPW = 4>
+template <typename T, int PART = 0, int RPW = 4, bool SYM = false>
 __global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
@@ -288,7 +371,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_has
     int bx, by;
     xcd_tile(bx, by);
     by += P.tile_y0;
-    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 
 #ifdef RAISR_EXP_PERSIST
