@@ -245,6 +245,11 @@ int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[3]);
  * (tests/test_gpu_certify.py samples that box).  Needs a configured context (the weights depend on the bit depth). */
 int raisr_hip_debug_approx_hash(raisr_hip_ctx *ctx, int pass_index, int hash_flavour, const float *abd, size_t n,
                                 uint8_t *bucket_out, uint8_t *cert_out, float *eps_out);
+/* Exhaustive self-check of the binary16 hash's folded thresholds ("Binary16 pipeline"): every operand pair the
+ * fast hash can see goes through the two divisions the reference has (VDIVPH) and through the comparisons that replace them;
+ * out[0] = disagreements (0 expected), out[1] = pairs compared.  Needs the pass's model. */
+int raisr_hip_debug_fold16_check(raisr_hip_ctx *ctx, int pass_index, unsigned long long out[2]);
+
 /* Hash bucket (0..215) of `n` host-side structure-tensor triples (a, b, d) x n with pass `pass_index`'s
  * thresholds, computed by the very device functions the hash kernel runs (fast path plus generic fall-back
  * for RAISR_HIP_HASH_AVX512; the RCPPS/RSQRTPS flavour for RAISR_HIP_HASH_AVX2).  Replaces nothing in the

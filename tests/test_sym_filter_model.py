@@ -105,3 +105,33 @@ def test_which_shipped_banks_are_palindromic():
     assert counts["filters_2x/filters_highres/filterbin_2_10_2"] == 2
     assert counts["filters_2x/filters_highres/filterbin_2_10"] == 50
     assert counts["filters_2x/filters_lowres/filterbin_2_8"] > 400      # not symmetric: the eight-load stage runs
+
+
+def test_shared_tree_of_sixteen_steps_gives_each_lane_its_step():
+    """filter_phase folds the row's 16 steps with ONE tree: after each level two steps are merged on a lane-index bit and the next
+    level runs once for both (level 2 pairs lanes inside their half of the row: row_shl:4 on even, row_shr:4 on odd partial sums).
+    Lane l must end with the reference's v of step bitrev4(l)."""
+    rng = np.random.default_rng(5)
+    acc = (rng.standard_normal((16, 16)) * 100).astype(f32)           # acc[s][lane]
+    want = [tree(list(acc[s]))[0] for s in range(16)]
+    lanes = range(16)
+    A = [[f32(acc[s][i] + acc[s][(i + 8) % 16]) for i in lanes] for s in range(16)]
+    B = []
+    for k in range(8):
+        t = [A[2 * k + 1][i] if i & 8 else A[2 * k][i] for i in lanes]
+        if k & 1:
+            B.append([f32(t[i] + (t[i - 4] if i - 4 >= 0 else f32(0))) for i in lanes])           # row_shr:4: lane i reads lane i - 4
+        else:
+            B.append([f32(t[i] + (t[i + 4] if i + 4 < 16 else f32(0))) for i in lanes])           # row_shl:4: lane i reads lane i + 4
+    C = []
+    for m in range(4):
+        t = [B[2 * m + 1][i] if i & 4 else B[2 * m][i] for i in lanes]
+        C.append([f32(t[i] + t[i ^ 2]) for i in lanes])
+    D = []
+    for n in range(2):
+        t = [C[2 * n + 1][i] if i & 2 else C[2 * n][i] for i in lanes]
+        D.append([f32(t[i] + t[i ^ 1]) for i in lanes])
+    v = [D[1][i] if i & 1 else D[0][i] for i in lanes]
+    for l in lanes:
+        sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3)
+        assert v[l].view(np.uint32) == want[sl].view(np.uint32), (l, sl)

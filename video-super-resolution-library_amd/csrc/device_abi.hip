@@ -105,6 +105,11 @@ struct ModelDev {
     // symmetric filter stage (kernels_filter.h, filter_phase<.., SYM>): which bank rows are NOT palindromes
     uint32_t* d_asym = nullptr;            // [32] bitmap over bucket * pixel_types + type (allocated with the first model)
     int asym_rows = -1;                    // number of set bits; -1 = not scanned (the symmetric kernel is never chosen then)
+    // binary16 pipeline: thresholds folded onto the dividends of the hash's strength and coherence divisions (Pass16)
+    uint16_t ls16[2] = {0x7e00, 0x7e00};
+    float cm16[2] = {0.f, 0.f};
+    int ct16[2] = {0, 0};
+    int fold16 = 0;
 };
 
 struct KernelTimer {
@@ -209,6 +214,7 @@ struct raisr_hip_ctx {
     hipEvent_t ev_kern = nullptr;
     bool ev_kern_valid = false;
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
     int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
@@ -507,13 +513,9 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     done(0, H);
 }
 
-// one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
-template <typename TOut>
-void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+// per-pass constants of the binary16 pipeline
+Pass16 make_pass16(raisr_hip_ctx* c, int pass, int W)
 {
-    const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
-    const int W = c->passW[pass], H = c->passH[pass];
-    PassParams P = make_pass(c, pass, W, H);
     const ModelDev& m = c->model[pass];
     Pass16 Q{};
     const int rows = m.h.hashkeys * m.h.pixel_types;
@@ -521,12 +523,25 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     Q.bank16_bytes = (int)blob_f16_bytes(rows);
     Q.tab16 = c->d_tab16;
     Q.qangle = m.h.qangle16; Q.qs0 = m.h.qstr16[0]; Q.qs1 = m.h.qstr16[1]; Q.qc0 = m.h.qcoh16[0]; Q.qc1 = m.h.qcoh16[1];
+    Q.ls0 = m.ls16[0]; Q.ls1 = m.ls16[1]; Q.cm0 = m.cm16[0]; Q.cm1 = m.cm16[1]; Q.ct0 = m.ct16[0]; Q.ct1 = m.ct16[1];
+    Q.fold = (c->fold16 && m.fold16) ? 1 : 0;
     {   // NF_8 / NF_10 (Raisr_globals.h:208-209; Raisr_AVX512FP16.cpp:146-151)
         const float maxv = c->cfg.bits == 8 ? 255.0f : 1023.0f;
         volatile float nf = 1.0f / (maxv * maxv * 2.0f * 2.0f);
         Q.nf = nf;
     }
     Q.c_avx = (W - 1) - ((W - 1) % 32) + 1;
+    return Q;
+}
+
+// one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
+template <typename TOut>
+void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+{
+    const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
+    const int W = c->passW[pass], H = c->passH[pass];
+    PassParams P = make_pass(c, pass, W, H);
+    const Pass16 Q = make_pass16(c, pass, W);
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
         dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
@@ -659,6 +674,7 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
@@ -795,6 +811,35 @@ int raisr_hip_pack_model_blob(void* host_blob, const float* bank, int hashkeys, 
     return RAISR_HIP_OK;
 }
 
+// Folded thresholds of the binary16 hash (kernels_fp16.h, Pass16).  Strength: ls = the smallest binary16 x with
+// qs <= fl16(x / 100) -- fl16(x / 100) is monotone in x, found by scanning all 63 490 non-NaN values with the correctly rounded
+// division (fp32 quotient rounded once more to binary16: innocuous, 24 >= 2 * 11 + 2).  Coherence: cm = midpoint between qc and
+// its predecessor, ct = 1 when that midpoint rounds to qc (qc's last mantissa bit is even); needs 0 < qc < inf.
+static void fold16_thresholds(ModelDev& m)
+{
+    auto h_of = [](uint16_t u) { _Float16 v; memcpy(&v, &u, 2); return v; };
+    m.fold16 = 1;
+    for (int i = 0; i < 2; i++) {
+        const _Float16 qs = h_of(m.h.qstr16[i]);
+        bool found = false;
+        _Float16 best = (_Float16)0.0f;
+        for (uint32_t u = 0; u < 65536u; u++) {
+            if ((u & 0x7c00u) == 0x7c00u && (u & 0x3ffu)) continue;              // NaN
+            const _Float16 x = h_of((uint16_t)u);
+            volatile float qf = (float)x / 100.0f;
+            const _Float16 f = (_Float16)qf;
+            if (qs <= f && (!found || x < best)) { best = x; found = true; }
+        }
+        uint16_t bits = 0x7e00;                                                   // NaN: no L1 passes
+        if (found) memcpy(&bits, &best, 2);
+        m.ls16[i] = bits;
+        const uint16_t qc = m.h.qcoh16[i];
+        if (qc == 0 || qc >= 0x7c00u) { m.fold16 = 0; continue; }               // zero, negative, infinite or NaN threshold: keep the divisions
+        m.cm16[i] = 0.5f * ((float)h_of(qc) + (float)h_of((uint16_t)(qc - 1)));  // exact: both binary16, their sum has <= 12 significant bits
+        m.ct16[i] = (qc & 1u) ? 0 : 1;
+    }
+}
+
 // Which rows of the fp32 bank are palindromes (f[k] == f[120 - k], compared as bit patterns)?  Decides whether the symmetric
 // filter stage may run for this model and lists the rows whose pixels it has to redo with all eight coefficient loads.
 // `host_bank` = the blob's fp32 bank [rows][128] on the host, or null: then it is read back from the device blob.
@@ -865,6 +910,7 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     HIP_TRY(hipMemcpyAsync(m.blob, device_blob, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     m.bytes = bytes; m.h = h; m.valid = true; m.bank_mfma_valid = false;
+    fold16_thresholds(m);
     if (int rc = scan_bank_symmetry(c, pass_index, nullptr)) return rc;
     return compute_zero_buckets(c, pass_index);
 }
@@ -915,6 +961,7 @@ int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int
     HIP_TRY(hipMemcpy(m.blob, host.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());           // frames run on non-blocking streams, which nothing orders after a null-stream copy
     m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true; m.bank_mfma_valid = false;
+    fold16_thresholds(m);
     if (int rc = scan_bank_symmetry(c, pass_index, (const float*)(host.data() + kBlobHeader))) return rc;
     return compute_zero_buckets(c, pass_index);
 }
@@ -1552,6 +1599,28 @@ int raisr_hip_debug_approx_hash(raisr_hip_ctx* c, int pass_index, int hash_flavo
     if (!rc && (hipMemcpy(bucket_out, d_out, n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(cert_out, d_out + n, n, hipMemcpyDeviceToHost) != hipSuccess))
         rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
     (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
+
+// Test hook: exhaustive comparison of the binary16 hash's folded thresholds (Pass16) with the divisions they replace, for
+// pass `pass_index`'s model.  out[0] = disagreements (must be 0), out[1] = operand pairs compared (~2^31).
+int raisr_hip_debug_fold16_check(raisr_hip_ctx* c, int pass_index, unsigned long long out[2])
+{
+    if (!c || pass_index < 0 || pass_index > 1 || !out) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (!c->model[pass_index].blob) return fail(RAISR_HIP_ESTATE, "model not set for this pass");
+    if (!c->model[pass_index].fold16) return fail(RAISR_HIP_ESTATE, "this model's thresholds are not folded (not positive finite numbers)");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, 2 * sizeof(unsigned long long)));
+    int rc = RAISR_HIP_OK;
+    if (hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemset");
+    if (!rc) {
+        const Pass16 Q = make_pass16(c, pass_index, 64);
+        hipLaunchKernelGGL(k_debug_fold16, dim3(65536), dim3(256), 0, c->stream, Q, d_out);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "k_debug_fold16");
+    }
+    if (!rc && hipMemcpy(out, d_out, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RAISR_HIP_ERUNTIME, "hipMemcpy");
+    (void)hipFree(d_out);
     return rc;
 }
 

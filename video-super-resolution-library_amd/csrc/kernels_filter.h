@@ -127,55 +127,67 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             }
             return tree16(acc);
         };
-        float keep = 0.0f;
         const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
-        // The 16 steps (4 adjacent pixels each) go in four groups {j, j+4, j+8, j+12}: the lane that keeps step s is
-        // l == s, so the four steps of a group end in four different quads of the pixel's 16 lanes.  Each step's
-        // accumulator is folded by the first two tree levels (row_ror 8, 4: every lane then holds r4[l & 3]), the four
-        // steps are merged quad-wise into one register (quad m <- step j+4m), and the last two levels, the accept
-        // test and the keep-select run once per group instead of once per step.  Same additions, same order.
-        const char* ctrq = ctr + 64 * (l >> 2);                // centre pixel of the step this lane's quad ends up with
+        // The row's 16 steps (4 adjacent pixels each) share ONE summation tree.  sumitup_ps_512 halves the number of distinct
+        // values per step at every level (16 lanes -> r8[0..7] -> r4[0..3] -> r2[0..1] -> v), so after each level two steps are
+        // merged into one register (v_cndmask on a lane-index bit) and the next level runs once for both: 16 + 8 + 4 + 2 adds
+        // and 8 + 4 + 2 + 1 merges per row, against 16 x 4 adds when every step folds on its own.  Same additions, same
+        // operands (level 2 uses row_shl:4 / row_shr:4 so that lanes pair inside their half of the row; a + b == b + a bit for
+        // bit).  Lane l ends up with the result of step sl = bitrev4(l): merge level 1 puts step bit 0 on lane bit 3, ..., level 4
+        // step bit 3 on lane bit 0.
+        float A16[16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float part[4];
+        for (int s = 0; s < 16; s++) {
+            const unsigned hA = sH[prow * TW + 4 * s + g];
+            // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
+            // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
+            const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
+            float acc;
+            if (!SYM) {
+                acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int s = j + 4 * m;
-                const unsigned hA = sH[prow * TW + 4 * s + g];
-                // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
-                // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
-                const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
-                float acc;
-                if (!SYM) {
-                    acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
-#pragma unroll
-                    for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
-                } else {
-                    const float q0 = RAISR_BANK_F(voff), q1 = RAISR_BANK_F(voff + 64u), q2 = RAISR_BANK_F(voff + 128u), q3 = RAISR_BANK_F(voff + 192u);
-                    acc = RAISR_LDS_F(tap[0], s) * q0;
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[2], s), q2, acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[3], s), q3, acc);
-                    acc = partner_xchg(acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), __uint_as_float(__float_as_uint(q3) & maskA), acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[5], s), q2, acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[6], s), q1, acc);
-                    acc = __builtin_fmaf(RAISR_LDS_F(tap[7], s), q0, acc);
-                }
-                acc = acc + row_ror<0x128>(acc);               // r8[i] = a[i] + a[i+8]
-                part[m] = acc + row_ror<0x124>(acc);           // r4[i] = r8[i] + r8[i+4]   (period 4 over the 16 lanes)
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+            } else {
+                const float q0 = RAISR_BANK_F(voff), q1 = RAISR_BANK_F(voff + 64u), q2 = RAISR_BANK_F(voff + 128u), q3 = RAISR_BANK_F(voff + 192u);
+                acc = RAISR_LDS_F(tap[0], s) * q0;
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[2], s), q2, acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[3], s), q3, acc);
+                acc = partner_xchg(acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), __uint_as_float(__float_as_uint(q3) & maskA), acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[5], s), q2, acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[6], s), q1, acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[7], s), q0, acc);
             }
-            float v = part[0];
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(part[3]), "s"(0xf000f000f000f000ull));
-            v = v + quad_perm<0x4e>(v);                        // [2,3,0,1]: r2 = r4[i] + r4[i+2]
-            v = v + quad_perm<0xb1>(v);                        // [1,0,3,2]: r2[0] + r2[1]
-            float res = RAISR_LDS_F(ctrq, j);
-            if (v > P.lo && v < P.hi) res = v;
-            // lane (g,l) keeps pixel column 4l+g, i.e. step l: in group j those are the lanes with (l & 3) == j
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keep) : "v"(res), "s"(0x1111111111111111ull << j));
+            A16[s] = acc + row_ror<0x128>(acc);                // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
         }
+#define RAISR_MERGE(dst, src, mask) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask))
+        float B8[8], C4[4], D2[2];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float t = A16[2 * k];
+            RAISR_MERGE(t, A16[2 * k + 1], 0xff00ff00ff00ff00ull);            // lanes 8..15 of every row: the odd step
+            // r4[i] = r8[i] + r8[i+4] inside each half; even k keeps lanes {0-3, 8-11} (row_shl:4), odd k lanes {4-7, 12-15} (row_shr:4)
+            B8[k] = (k & 1) ? t + row_ror<0x114>(t) : t + row_ror<0x104>(t);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            float t = B8[2 * m];
+            RAISR_MERGE(t, B8[2 * m + 1], 0xf0f0f0f0f0f0f0f0ull);
+            C4[m] = t + quad_perm<0x4e>(t);                    // [2,3,0,1]: r2 = r4[i] + r4[i+2]
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            float t = C4[2 * n];
+            RAISR_MERGE(t, C4[2 * n + 1], 0xccccccccccccccccull);
+            D2[n] = t + quad_perm<0xb1>(t);                    // [1,0,3,2]: r2[0] + r2[1]
+        }
+        float v = D2[0];
+        RAISR_MERGE(v, D2[1], 0xaaaaaaaaaaaaaaaaull);
+#undef RAISR_MERGE
+        const int sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);     // the step whose pixel this lane keeps
+        float keep = RAISR_LDS_F(ctr, sl);
+        if (v > P.lo && v < P.hi) keep = v;
         if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
             const unsigned hrow = sH[prow * TW + lane];
             const unsigned key = hrow * (unsigned)P.pixel_types + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
@@ -186,7 +198,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
                 for (int s = 0; s < 16; s++) {
                     if (((am >> (4 * s)) & 0xFull) == 0) continue;
                     const float v = plain_step(s, sH[prow * TW + 4 * s + g]);
-                    if (s == l && ((am >> (4 * s + g)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
+                    if (s == sl && ((am >> (4 * s + g)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
                 }
             }
         }
@@ -196,7 +208,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
                 const unsigned hB = sH2[prow * TW + 4 * s + g];
                 if (hB == 0xFFu) continue;
                 const float v = plain_step(s, hB);
-                if (s == l) {
+                if (s == sl) {
                     if (v > P.lo && v < P.hi) keep = v;
                     else if (P.randomness) keep = RAISR_LDS_F(ctr, s);
                 }
@@ -204,7 +216,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         }
 #undef RAISR_LDS_F
 #undef RAISR_BANK_F
-        const int c = c0 + 4 * l + g;
+        const int c = c0 + 4 * sl + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
 }

@@ -26,6 +26,17 @@ struct Pass16 {
     uint16_t qangle, qs0, qs1, qc0, qc1;   // binary16 bit patterns
     float nf;                    // NF_8 (fp32), Raisr_globals.h:208
     int c_avx;                   // first column of the blend stage's scalar (fp32) tail
+    // Folded thresholds (fold16_thresholds, device_abi.hip): two of the hash's three binary16 divisions only feed comparisons
+    // with constants, and x -> fl16(x / c) is monotone, so the comparisons are made on the dividends instead:
+    //   [qs <= fl16(L1 / 100)]  ==  [L1 >= ls]         ls = the smallest binary16 L1 that passes (NaN bits: none does)
+    //   [qc <= fl16(n / d)]     ==  [n >= cm d] or [n > cm d]   for d > 0, cm = the lower rounding boundary of qc (the midpoint
+    //                               below it; exact in fp32, and so is cm d: 12 + 11 significant bits), ct = 1 when the
+    //                               midpoint itself rounds to qc (ties to even)
+    // fold = 0 (thresholds that are not positive finite numbers): the divisions stay.
+    uint16_t ls0, ls1;
+    float cm0, cm1;
+    int ct0, ct1;
+    int fold;
 };
 
 __device__ __forceinline__ hf h_bits(uint16_t u) { return __builtin_bit_cast(hf, u); }
@@ -121,7 +132,7 @@ __device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab, bool& rare)
 // GetHashValue_AVX512FP16_16h_{8,32}Elements (Raisr_AVX512FP16.cpp:382-471,497-590).  FAST: branch-free square roots,
 // `rare` set when one of them saw an infinity or a NaN (the caller then calls the generic variant).
 // thresholds BY VALUE: a reference into the kernel-argument struct would force it into scratch for the out-of-line variant
-struct HashQ16 { uint16_t qangle, qs0, qs1, qc0, qc1; };
+struct HashQ16 { uint16_t qangle, qs0, qs1, qc0, qc1, ls0, ls1; float cm0, cm1; int ct0, ct1, fold; };
 
 template <bool FAST>
 __device__ __forceinline__ int hash_px16_impl(hf a, hf b, hf d, const HashQ16 Q, const uint16_t* tab, bool& rare)
@@ -154,13 +165,23 @@ __device__ __forceinline__ int hash_px16_impl(hf a, hf b, hf d, const HashQ16 Q,
     ang = (b < (hf)0.0f) ? nang : ang;
     ang = ang + ((ang < (hf)0.0f) ? pi : (hf)0.0f);
     const hf sL1 = root(L1), sL2 = root(L2);
-    const hf coh = h_div(sL1 - sL2, (sL1 + sL2) + near_zero);
-    const hf str = h_div(L1, c100);
     const float fl = __builtin_floorf((float)(ang * h_bits(Q.qangle)));
     int ai = (fl >= -32768.0f && fl <= 32767.0f) ? (int)fl : -32768;     // cvt_roundph_epi16, TO_NEG_INF
     ai = min(23, max(ai, 0));
-    const int si = (int)(h_bits(Q.qs0) <= str) + (int)(h_bits(Q.qs1) <= str);
-    const int ci = (int)(h_bits(Q.qc0) <= coh) + (int)(h_bits(Q.qc1) <= coh);
+    int si, ci;
+    if (FAST && Q.fold) {
+        // (finite operands only: the caller redoes pixels that saw an infinity or a NaN -- `rare` -- with the divisions)
+        si = (int)(L1 >= h_bits(Q.ls0)) + (int)(L1 >= h_bits(Q.ls1));
+        const float nf = (float)(sL1 - sL2), df = (float)((sL1 + sL2) + near_zero);
+        const float b0 = Q.cm0 * df, b1 = Q.cm1 * df;                     // exact products
+        const bool dpos = df > 0.0f;                                      // d == 0 means sL1 == sL2 == 0: 0 / 0, no threshold passes
+        ci = (int)(dpos && (Q.ct0 ? nf >= b0 : nf > b0)) + (int)(dpos && (Q.ct1 ? nf >= b1 : nf > b1));
+    } else {
+        const hf coh = h_div(sL1 - sL2, (sL1 + sL2) + near_zero);
+        const hf str = h_div(L1, c100);
+        si = (int)(h_bits(Q.qs0) <= str) + (int)(h_bits(Q.qs1) <= str);
+        ci = (int)(h_bits(Q.qc0) <= coh) + (int)(h_bits(Q.qc1) <= coh);
+    }
     return ai * 9 + si * 3 + ci;
 }
 
@@ -168,6 +189,39 @@ __device__ __attribute__((noinline)) int hash_px16_generic(hf a, hf b, hf d, con
 {
     bool unused = false;
     return hash_px16_impl<false>(a, b, d, Q, tab, unused);
+}
+
+// Test hook: the folded thresholds against the divisions they replace, EXHAUSTIVELY.  Strength: all 65 536 bit patterns of L1.
+// Coherence: every pair (n, d) of binary16 bit patterns with d > 0 finite and n finite -- the pairs the fast hash can see; d is a
+// sum of two VRCPPH(VRSQRTPH(.)) results, >= 0 or NaN, and d == 0 implies n == 0 -- plus NaN operands.  Counts disagreements.
+__global__ __launch_bounds__(256) void k_debug_fold16(Pass16 Q, unsigned long long* __restrict__ out)
+{
+    const unsigned d_bits = blockIdx.x;                         // 0 .. 65535
+    const hf dd = h_bits((uint16_t)d_bits);
+    const hf c100 = (hf)100.0f;
+    unsigned long long bad = 0, pairs = 0;
+    const bool d_nan = (d_bits & 0x7c00u) == 0x7c00u && (d_bits & 0x3ffu);
+    const bool d_ok = (d_bits > 0u && d_bits < 0x7c00u) || d_nan;          // positive finite, or NaN
+    for (unsigned n_bits = threadIdx.x; n_bits < 65536u; n_bits += 256u) {
+        const hf nn = h_bits((uint16_t)n_bits);
+        if (d_bits == 0u) {                                     // this block also sweeps the strength comparison (n_bits plays L1)
+            const hf str = h_div(nn, c100);
+            const int s_div = (int)(h_bits(Q.qs0) <= str) + (int)(h_bits(Q.qs1) <= str);
+            const int s_fold = (int)(nn >= h_bits(Q.ls0)) + (int)(nn >= h_bits(Q.ls1));
+            bad += s_div != s_fold; pairs++;
+        }
+        const bool n_inf = (n_bits & 0x7fffu) == 0x7c00u;
+        if (!d_ok || n_inf) continue;
+        const hf coh = h_div(nn, dd);
+        const int c_div = (int)(h_bits(Q.qc0) <= coh) + (int)(h_bits(Q.qc1) <= coh);
+        const float nf = (float)nn, df = (float)dd;
+        const float b0 = Q.cm0 * df, b1 = Q.cm1 * df;
+        const bool dpos = df > 0.0f;
+        const int c_fold = (int)(dpos && (Q.ct0 ? nf >= b0 : nf > b0)) + (int)(dpos && (Q.ct1 ? nf >= b1 : nf > b1));
+        bad += c_div != c_fold; pairs++;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], pairs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,7 +319,7 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
     hf2 *t1A = t1_[0], *t1B = t1_[1], *t1D = t1_[2];
 
     const int c = c0 + lane;
-    const HashQ16 HQ = {Q.qangle, Q.qs0, Q.qs1, Q.qc0, Q.qc1};
+    const HashQ16 HQ = {Q.qangle, Q.qs0, Q.qs1, Q.qc0, Q.qc1, Q.ls0, Q.ls1, Q.cm0, Q.cm1, Q.ct0, Q.ct1, Q.fold};
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const hf2 a2 = (holdA[p] + curA[p]) + t1A[p];
@@ -330,19 +384,24 @@ __device__ __forceinline__ hf row_ror_h(hf v)
 
 // filter16_phase: one 64 x 16 tile once its LR window is in LDS (sL points at window position (r0-5, c0-5), row
 // stride LW) and its hashes are in sH.
-template <int LW>
+// PAIRS: the window comes as two arrays of packed pairs instead of single samples (build_pair_windows below), so that the two
+// samples of a tap pair (k, k + 16) arrive with ONE ds_read_b32 instead of two ds_read_u16 and a v_perm to pack them.
+template <int LW, bool PAIRS = false>
 __device__ __forceinline__ void filter16_phase(const PassParams& P, const Pass16& Q, const hf* sL, const uint8_t* sH,
-                                               int c0, int r0, uint16_t* __restrict__ hr)
+                                               int c0, int r0, uint16_t* __restrict__ hr, const uint32_t* sPA = nullptr, const uint32_t* sPB = nullptr)
 {
     constexpr int TW = 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
     int off0[4], off1[4];
+    const uint32_t* pbase[4];                                          // PAIRS: array (A or B) and offset of the lane's pair per chunk
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
         const int k0 = 32 * ch + l, k1 = k0 + 16;
         off0[ch] = (k0 < kTaps) ? (k0 / 11) * LW + (k0 % 11) : 0;     // padding taps: coefficient is +0
         off1[ch] = (k1 < kTaps) ? (k1 / 11) * LW + (k1 % 11) : 0;
+        // tap k0 + 16 sits one patch row down and 5 columns right of tap k0 (array A), or two rows down and 6 columns left (B)
+        if (PAIRS) pbase[ch] = ((k0 % 11) + 5 < 11 ? sPA : sPB) + (k0 / 11) * LW + (k0 % 11);
     }
     const hf lo = (hf)P.lo, hi = (hf)P.hi;
     // bounds-checked 32-bit addressing of the binary16 bank: an unfiltered pixel's hash (0xFF) points past it and
@@ -367,42 +426,65 @@ __device__ __forceinline__ void filter16_phase(const PassParams& P, const Pass16
             tp0[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off0[ch]);
             tp1[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off1[ch]);
         }
-        const char* ctrq = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5) + 32 * (l >> 2);
-#define RAISR_LDS_H(p, s) (*reinterpret_cast<const hf*>((p) + 8 * (s)))
-        // steps grouped {j, j+4, j+8, j+12} as in filter_phase: two tree levels per step, quad-wise merge, the rest per group
+        const char* ctr = PAIRS ? reinterpret_cast<const char*>(sPA + prow * LW + g + 5 * LW + 5)      // low half of a pair = the sample itself
+                                : reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
+        const char* tpp[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            unsigned part[4];
+        for (int ch = 0; ch < 4; ch++) tpp[ch] = reinterpret_cast<const char*>(PAIRS ? pbase[ch] + prow * LW + g : nullptr);
+#define RAISR_LDS_H(p, s) (*reinterpret_cast<const hf*>((p) + (PAIRS ? 16 : 8) * (s)))
+#define RAISR_LDS_PAIR(ch, s) (PAIRS ? __builtin_bit_cast(hf2, *reinterpret_cast<const uint32_t*>(tpp[ch] + 16 * (s))) \
+                                     : (hf2){*reinterpret_cast<const hf*>(tp0[ch] + 8 * (s)), *reinterpret_cast<const hf*>(tp1[ch] + 8 * (s))})
+        // one summation tree for the row's 16 steps, as in filter_phase: after every level two steps are merged into one register
+        // and the next level runs once for both (the level-2 pairs stay inside their half of the row: row_shl:4 / row_shr:4);
+        // lane l ends up with step sl = bitrev4(l)
+        unsigned A16[16];
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int s = j + 4 * m;
-                const unsigned hA = sH[prow * TW + 4 * s + g];
-                const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;
-                hf2 acc = (hf2){RAISR_LDS_H(tp0[0], s), RAISR_LDS_H(tp1[0], s)} *
-                          __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff, 0, 0));
+        for (int s = 0; s < 16; s++) {
+            const unsigned hA = sH[prow * TW + 4 * s + g];
+            const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;
+            hf2 acc = RAISR_LDS_PAIR(0, s) * __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff, 0, 0));
 #pragma unroll
-                for (int ch = 1; ch < 4; ch++)
-                    acc = __builtin_elementwise_fma((hf2){RAISR_LDS_H(tp0[ch], s), RAISR_LDS_H(tp1[ch], s)},
-                                                    __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff + 64u * ch, 0, 0)), acc);
-                hf v = acc.x + acc.y;                       // a[l] + a[l+16]
-                v = v + row_ror_h<0x128>(v);                // r16[i] + r16[i+8]
-                v = v + row_ror_h<0x124>(v);                // r8[i] + r8[i+4]   (period 4 over the 16 lanes)
-                part[m] = h_u(v);
-            }
-            unsigned vb = part[0];
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[1]), "s"(0x00f000f000f000f0ull));
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[2]), "s"(0x0f000f000f000f00ull));
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(vb) : "v"(part[3]), "s"(0xf000f000f000f000ull));
-            hf v = h_bits((uint16_t)vb);
-            v = v + row_ror_h<0x4e>(v);                     // quad_perm [2,3,0,1]: t[i] + t[i+2]
-            v = v + row_ror_h<0xb1>(v);                     // quad_perm [1,0,3,2]: s0 + s1
-            hf res = RAISR_LDS_H(ctrq, j);
-            if (v > lo && v < hi) res = v;
-            const unsigned rb = h_u(res);
-            asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(keepb) : "v"(rb), "s"(0x1111111111111111ull << j));
+            for (int ch = 1; ch < 4; ch++)
+                acc = __builtin_elementwise_fma(RAISR_LDS_PAIR(ch, s),
+                                                __builtin_bit_cast(hf2, __builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, voff + 64u * ch, 0, 0)), acc);
+            hf v = acc.x + acc.y;                           // a[l] + a[l+16]
+            v = v + row_ror_h<0x128>(v);                    // r16[i] + r16[i+8]
+            A16[s] = h_u(v);
         }
+#define RAISR_MERGE(dst, src, mask) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask))
+        unsigned B8[8], C4[4], D2[2];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            unsigned t = A16[2 * k];
+            RAISR_MERGE(t, A16[2 * k + 1], 0xff00ff00ff00ff00ull);
+            const hf x = h_bits((uint16_t)t);
+            B8[k] = h_u((k & 1) ? x + row_ror_h<0x114>(x) : x + row_ror_h<0x104>(x));     // r8[i] + r8[i+4]
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            unsigned t = B8[2 * m];
+            RAISR_MERGE(t, B8[2 * m + 1], 0xf0f0f0f0f0f0f0f0ull);
+            const hf x = h_bits((uint16_t)t);
+            C4[m] = h_u(x + row_ror_h<0x4e>(x));              // quad_perm [2,3,0,1]: t[i] + t[i+2]
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            unsigned t = C4[2 * n];
+            RAISR_MERGE(t, C4[2 * n + 1], 0xccccccccccccccccull);
+            const hf x = h_bits((uint16_t)t);
+            D2[n] = h_u(x + row_ror_h<0xb1>(x));              // quad_perm [1,0,3,2]: s0 + s1
+        }
+        unsigned vb = D2[0];
+        RAISR_MERGE(vb, D2[1], 0xaaaaaaaaaaaaaaaaull);
+#undef RAISR_MERGE
+        const hf v = h_bits((uint16_t)vb);
+        const int sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
+        hf res = RAISR_LDS_H(ctr, sl);
+        if (v > lo && v < hi) res = v;
+        keepb = h_u(res);
 #undef RAISR_LDS_H
-        const int c = c0 + 4 * l + g;
+#undef RAISR_LDS_PAIR
+        const int c = c0 + 4 * sl + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = (uint16_t)keepb;
     }
 }
@@ -428,17 +510,49 @@ __global__ __launch_bounds__(256) void k_filter16(const T* __restrict__ lr, cons
     filter16_phase<LW>(P, Q, sL, sH, c0, r0, hr);
 }
 
-// k_hashfilter16: both binary16 stages of a tile in one launch (see k_hashfilter).
+// Pair windows of the fused kernel's filter stage.  w = the 26 x 74 window of the tile (origin (r0-5, c0-5), inside the staged
+// 28 x 77 window sW = sL + LW + 1).  A[y][x] = (w[y][x], w[y+1][x+5]), B[y][x] = (w[y][x], w[y+2][x-6]), row stride LW, as
+// packed binary16 pairs.  Entries no tap pair ever reads are left out (A: x > 68; B: x < 6 or y = 25) -- their partner would lie
+// outside the staged window.  Wave w builds rows w, w + 4, ...; lane = column (plus the ten columns 64..73 for lanes < 10).
+template <int LW>
+__device__ __forceinline__ void build_pair_windows(const hf* sW, uint32_t* sPA, uint32_t* sPB)
+{
+    const int lane = threadIdx.x & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(wu >= 0 && wu < 4);
+    auto one = [&](int y, int x) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(sW + y * LW + x);
+        const uint32_t a = p[0];
+        if (x <= 68) sPA[y * LW + x] = a | ((uint32_t)p[LW + 5] << 16);
+        if (x >= 6 && y < 25) sPB[y * LW + x] = a | ((uint32_t)p[2 * LW - 6] << 16);
+    };
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int y = wu + 4 * i;
+        if (y < 26) {
+            one(y, lane);
+            if (lane < 10) one(y, 64 + lane);
+        }
+    }
+}
+
+// k_hashfilter16: both binary16 stages of a tile in one launch (see k_hashfilter).  The hash stage's gradient tile and tables and
+// the filter stage's pair windows share one LDS region (a workgroup barrier on either side of build_pair_windows).
 template <typename T>
 __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
                                                          uint8_t* __restrict__ hash_out, uint16_t* __restrict__ hr)
 {
     constexpr int R = 4, TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12;
+    constexpr int kGBytes = (TH + 9) * 74 * 8, kTabBytes = 3072 * 2, kPairBytes = 26 * LW * 4;
+    static_assert(2 * kPairBytes <= kGBytes + kTabBytes, "the pair windows fit the hash stage's region");
     __shared__ hf sL[LH * LW];
-    __shared__ uint2 sG[(TH + 9) * 74];
-    __shared__ uint16_t sTab[3072];
-    __shared__ uint8_t sH[TH * TW];          // rows [4w, 4w+4) are written and read by wave w only: no barrier between the stages
+    __shared__ __attribute__((aligned(16))) unsigned char sRegion[kGBytes + kTabBytes];
+    uint2* sG = reinterpret_cast<uint2*>(sRegion);
+    uint16_t* sTab = reinterpret_cast<uint16_t*>(sRegion + kGBytes);
+    uint32_t* sPA = reinterpret_cast<uint32_t*>(sRegion);
+    uint32_t* sPB = reinterpret_cast<uint32_t*>(sRegion + kPairBytes);
+    __shared__ uint8_t sH[TH * TW];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
@@ -456,8 +570,10 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
         const int r = r0 + w * R + j;
         if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA[j];
     }
-    __builtin_amdgcn_wave_barrier();
-    filter16_phase<LW>(P, Q, sL + LW + 1, sH, c0, r0, hr);
+    __syncthreads();                                         // every wave is done with the gradient tile and the tables
+    build_pair_windows<LW>(sL + LW + 1, sPA, sPB);
+    __syncthreads();
+    filter16_phase<LW, true>(P, Q, sL + LW + 1, sH, c0, r0, hr, sPA, sPB);
 }
 
 

@@ -18,7 +18,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libraisr_hip.so")
+# RAISR_HIP_LIB: an experimental build of the same library (scripts/build_exp.sh) for A/B runs on one GPU box; never a fallback
+_SO = os.environ.get("RAISR_HIP_LIB") or os.path.join(_HERE, "libraisr_hip.so")
 _LIB = None
 
 # RaisrDefaults.h enums
@@ -130,6 +131,7 @@ def lib():
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_debug_fold16_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_use_streams.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -403,6 +405,12 @@ class RaisrDevice:
         out = np.zeros(abd.shape[0], np.uint8)
         _check(lib().raisr_hip_debug_hash(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
         return out
+
+    def debug_fold16_check(self, pass_index=0):
+        """(disagreements, pairs compared) of the binary16 hash's folded thresholds vs the divisions, exhaustive on the device"""
+        out = (ctypes.c_ulonglong * 2)()
+        _check(lib().raisr_hip_debug_fold16_check(self._h, pass_index, out), "debug_fold16_check")
+        return int(out[0]), int(out[1])
 
     def debug_approx_hash(self, abd, pass_index=0, flavour=HASH_AVX512):
         """(bucket, certified, eps) of the certified hash stage for an (n, 3) float32 array of approximate tensor triples."""
