@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--frames-per-step", type=int, default=768,
                     help="frames per step (batch); the default keeps the timed region of the default run >= 2 s")
     ap.add_argument("--lanes", type=int, default=4, help="frames in flight per GPU (one context+stream each); 2-4 measure within 2 %%")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (raisr_hip_process_y_device_batch); 0 = auto: 8 for outputs up to 1080p "
+                    "(C1, C4: one launch of one small frame cannot fill the chip), 1 above")
     ap.add_argument("--passes", type=int, default=0, help="override the config's pass count (1 or 2)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration; the bench line is C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,9 +276,13 @@ def respawn_ranks(args):
     os.execv(sys.executable, cmd)
 
 
-def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmup, fence, timing, fast=None):
-    """Frames resident in HBM -> output planes in HBM, `lanes_n` frames in flight.  Returns (seconds, kernel timings,
-    lanes, device inputs/outputs)."""
+def auto_batch(wl):
+    return 8 if wl.out_w * wl.out_h <= 1920 * 1080 else 1
+
+
+def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmup, fence, timing, fast=None, batch=1):
+    """Frames resident in HBM -> output planes in HBM, `lanes_n` launches in flight, `batch` frames per launch (one launch per
+    kernel for the whole batch: raisr_hip_process_y_device_batch).  Returns (seconds, kernel timings, lanes, device inputs/outputs)."""
     dev = torch.device("cuda", gpu)
     lanes = []
     for _ in range(lanes_n):
@@ -287,12 +293,30 @@ def device_loop(R, torch, wl, gpu, blobs, lanes_n, host_frames, nf, steps, warmu
         if fast is not None:
             d.set_fast(fast)
         lanes.append(d)
-    d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
-    d_out = [torch.empty((wl.out_h, wl.out_w), dtype=torch.uint8 if wl.bps == 1 else torch.uint16, device=dev) for _ in range(lanes_n)]
+    tdt = torch.uint8 if wl.bps == 1 else torch.uint16
+    if batch > 1:
+        # the batch entry wants equally spaced planes: the frames in one allocation, every lane's outputs in another
+        while len(host_frames) % batch:
+            host_frames = host_frames + host_frames[:batch - len(host_frames) % batch]
+        hs = np.stack(host_frames)
+        all_in = torch.from_numpy(hs.view(np.int16) if wl.bps == 2 else hs).to(dev).view(tdt)
+        d_in = [all_in[i] for i in range(all_in.shape[0])]
+        out_blocks = [torch.empty((batch, wl.out_h, wl.out_w), dtype=tdt, device=dev) for _ in range(lanes_n)]
+        d_out = [b[0] for b in out_blocks]
+        in_ptrs = [[d_in[g * batch + i].data_ptr() for i in range(batch)] for g in range(len(d_in) // batch)]
+        out_ptrs = [[b[i].data_ptr() for i in range(batch)] for b in out_blocks]
+    else:
+        d_in = [torch.from_numpy(f).to(dev) for f in host_frames]
+        d_out = [torch.empty((wl.out_h, wl.out_w), dtype=tdt, device=dev) for _ in range(lanes_n)]
     torch.cuda.synchronize()
     uniq = len(d_in)
 
     def step():
+        if batch > 1:
+            for k in range(nf // batch):                       # nf is a multiple of the batch (main() rounds it)
+                ln = k % lanes_n
+                lanes[ln].process_y_batch(in_ptrs[k % len(in_ptrs)], wl.in_w * wl.bps, out_ptrs[ln], wl.out_w * wl.bps)
+            return
         for f in range(nf):
             ln = f % lanes_n
             lanes[ln].process_y(d_in[f % uniq].data_ptr(), wl.in_w * wl.bps, d_out[ln].data_ptr(), wl.out_w * wl.bps)
@@ -331,7 +355,7 @@ def filtered_zone_px(w, h):
     return max(0, c_final - 6) * max(0, h - 12)
 
 
-def roofline_of(wl, kern, iso, lanes_n):
+def roofline_of(wl, kern, iso, lanes_n, batch=1):
     """`roofline` object of one workload from the HIP-event timings of its kernels: `kern` = per-kernel totals over the timed
     region (lanes_n frames in flight), `iso` = per-launch milliseconds of the same kernels with nothing else on the chip."""
     roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
@@ -340,7 +364,7 @@ def roofline_of(wl, kern, iso, lanes_n):
         return roofline
     per_launch = kern[dom]["total_ms"] / kern[dom]["count"] * 1e-3           # seconds
     launches_per_frame = wl.passes                                           # one launch of the dominant kernel = one pass of one frame
-    achieved = wl.algo_bytes / launches_per_frame / per_launch / 1e9
+    achieved = wl.algo_bytes * batch / launches_per_frame / per_launch / 1e9   # (of `batch` frames when the batch entry is in use)
     traffic, traffic_src = measured_traffic(dom, wl.name)
     # NOTE: `avg_launch_ms` is measured while `lanes` frames are in flight, so launches of different lanes share the
     # chip and each one is stretched accordingly; `isolated_launch_ms` is the same launch alone on the chip (the duration
@@ -349,7 +373,8 @@ def roofline_of(wl, kern, iso, lanes_n):
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(per_launch * 1e3, 4),
                 "isolated_launch_ms": round(iso[dom], 4) if dom in iso else None,
-                "algorithmic_bytes_per_launch": wl.algo_bytes // launches_per_frame,
+                "algorithmic_bytes_per_launch": wl.algo_bytes * batch // launches_per_frame,
+                "frames_per_launch": batch,
                 "lanes_overlapped": lanes_n,
                 "note": "path is vector-L1 / fp32-VALU / LDS bound (~1.3 kFLOP and 512 B of L1-delivered coefficients per output pixel vs 1.25 "
                         "compulsory bytes); the HBM fraction is reported as required, roofline.l1 and roofline.valu are the binding figures (DESIGN.md s5)"}
@@ -582,22 +607,25 @@ def certify_leg(R, wl, gpu, blobs, frames):
     return res
 
 
-def config_leg(R, torch, name, gpu, load_blobs, lanes_n, n_frames, fence, kind):
+def config_leg(R, torch, name, gpu, load_blobs, lanes_n, n_frames, fence, kind, batch=0):
     """One BASELINE.json configuration as first-class evidence: the headline loop (frames resident in HBM, `lanes_n` in flight),
     per-kernel HIP-event timings, isolated launch durations, both rooflines, and the certified hash stage's self-check on the
     frames that ran."""
     w = Workload(name)
     b = load_blobs(w)
     frames = w.frames(kind, range(8 if w.out_w <= 3840 else 4))
-    dt, kern, lanes, d_in, d_out = device_loop(R, torch, w, gpu, b, lanes_n, frames, n_frames, 1, 1, fence, True)
+    batch = batch or auto_batch(w)
+    n_frames = max(batch, n_frames // batch * batch)
+    dt, kern, lanes, d_in, d_out = device_loop(R, torch, w, gpu, b, lanes_n, frames, n_frames, 1, 1, fence, True, batch=batch)
     iso = isolated_kernel_ms(lanes, d_in, d_out, w, torch, iters=12)
     for d in lanes:
         d.close()
     del d_in, d_out
     fps = n_frames / dt
     return {"workload": w.desc, "fps": round(fps, 2), "value": round(w.out_w * w.out_h * fps / 1e6, 2), "unit": "MP/s", "frames": n_frames,
+            "frames_per_launch": batch,
             "kernels_isolated_ms": {k: round(v, 4) for k, v in iso.items()},
-            "roofline": roofline_of(w, kern, iso, lanes_n),
+            "roofline": roofline_of(w, kern, iso, lanes_n, batch),
             "certify": certify_leg(R, w, gpu, b, frames[:4])}
 
 
@@ -679,12 +707,14 @@ def main():
         lanes = []
         host_frames = wl.frames(args.frame_kind, range(4))
     else:
+        batch = args.batch or auto_batch(wl)
+        nf = max(batch, nf // batch * batch)
         uniq = min(nf, 8)
         # each rank owns its own frames of the (virtual) stream: frame index = rank + world * i
         mine = sharding.frames_for_rank(uniq * world, rank, world)
         host_frames = wl.frames(args.frame_kind, mine)
         dt, kern, lanes, d_in, d_out = device_loop(R, torch, wl, gpu, blobs, args.lanes, host_frames, nf, args.steps, args.warmup,
-                                                   fence, timing)
+                                                   fence, timing, batch=batch)
         dt_ranks = sharding.gather_over_ranks(dt, dev, dist if use_dist else None)
         dt = sharding.max_over_ranks(dt, dev, dist if use_dist else None)
         frames_total = nf * args.steps * world
@@ -713,7 +743,7 @@ def main():
         assert abs(fps_job - frames_total / dt) <= 1e-6 * fps_job
         mp_s = wl.out_w * wl.out_h * fps_job / 1e6
         kernels_ms = {k: round(v["total_ms"] / max(1, v["count"]), 4) for k, v in kern.items()}
-        roofline = roofline_of(wl, kern, iso, args.lanes)
+        roofline = roofline_of(wl, kern, iso, args.lanes, args.batch or auto_batch(wl))
         fast_level = lanes[0].fast() if lanes and hasattr(lanes[0], "fast") else int(os.environ.get("RAISR_HIP_FAST", "0") or 0)
         for d in lanes:
             d.close()
@@ -751,7 +781,7 @@ def main():
                                "certify": extras.get("parity", {}).get("certify")}}
                 for cname in ("C1", "C3", "C4", "C5"):
                     try:
-                        cfgs[cname] = config_leg(R, torch, cname, gpu, load_blobs, args.lanes, args.extra_frames if cname != "C5" else max(32, args.extra_frames // 4), fence, args.frame_kind)
+                        cfgs[cname] = config_leg(R, torch, cname, gpu, load_blobs, args.lanes, args.extra_frames if cname != "C5" else max(32, args.extra_frames // 4), fence, args.frame_kind, args.batch)
                     except Exception as e:
                         cfgs[cname] = {"value": None, "error": f"{type(e).__name__}: {e}"}
                 extras["configs"] = cfgs
@@ -799,7 +829,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl.name}: {wl.desc}, CT blend, {where}" + (f" [passes={wl.passes}]" if args.passes else ""),
                        "frame_kind": args.frame_kind, "mode": "exact" if not fast_level else f"fast-{fast_level} (NOT bit-exact: RAISR_HIP_FAST is set)",
-                       "frames_per_step": nf, "lanes": args.lanes, "fps": round(frames_total / dt, 2),
+                       "frames_per_step": nf, "lanes": args.lanes, "frames_per_launch": args.batch or auto_batch(wl), "fps": round(frames_total / dt, 2),
                        "timed_region_s": round(dt, 3),
                        "parallelism": f"frame-shard x{world}"} |
                       ({"numa_ranks": numa_ranks, "fps_per_rank": {"min": round(min(fps_ranks), 2), "max": round(max(fps_ranks), 2),

@@ -104,6 +104,15 @@ int raisr_hip_set_blending(raisr_hip_ctx *ctx, int blending);
  * context's own stream).  Asynchronous: returns after enqueueing. */
 int raisr_hip_process_y_device(raisr_hip_ctx *ctx, const void *d_in, size_t in_pitch,
                                void *d_out, size_t out_pitch, void *stream);
+/* Frame batch: n Y planes of the configured geometry, device-resident, through ONE launch per kernel (the frame index is the
+ * launch's third grid dimension; scratch planes are kept n deep).  For small frames -- 540p, 720p -- whose single launches cannot
+ * fill the chip.  The one-launch path needs the planes equally spaced in memory (d_in[i] - d_in[i-1] and d_out[i] - d_out[i-1]
+ * constant and positive: the planes of one allocation) and n <= RAISR_HIP_MAX_BATCH; other batches, and pipelines selected by
+ * the A/B switches, run frame by frame.  Same bits either way.  The reference has no counterpart (RNLProcess takes one frame,
+ * Library/Raisr.cpp:1294); north_star asks for frame batches. */
+#define RAISR_HIP_MAX_BATCH 16
+int raisr_hip_process_y_device_batch(raisr_hip_ctx *ctx, int n, const void *const *d_in, size_t in_pitch,
+                                     void *const *d_out, size_t out_pitch, void *stream);
 /* cheap upscale of one plane (chroma path of RNLProcess): src/dst sample type from `bits` */
 int raisr_hip_resize_plane_device(raisr_hip_ctx *ctx, const void *d_src, int sw, int sh, size_t spitch,
                                   void *d_dst, int dw, int dh, size_t dpitch, int bits, void *stream);

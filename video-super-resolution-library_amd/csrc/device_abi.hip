@@ -246,6 +246,11 @@ struct raisr_hip_ctx {
     void* d_mid = nullptr;                      // two-pass intermediate (sample type), only when the passes differ in size
     const void* lr0_alias = nullptr;            // set per frame: pass 1 runs at input size on a tightly pitched input plane -> no copy into d_lr[0]
     int passW[2] = {0, 0}, passH[2] = {0, 0};
+    // frame batches (raisr_hip_process_y_device_batch): the scratch planes exist batch_cap times, back to back; zb_* describe the
+    // batch of the call in progress (1 / 0 / 0 outside one)
+    int batch_cap = 1;
+    int zb_n = 1;
+    size_t zb_in_stride = 0, zb_out_stride = 0;      // elements between consecutive caller planes
     GaussW gauss{};
     // device staging for raisr_hip_process_host
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
@@ -295,24 +300,24 @@ ResizeParams make_resize(int sw, int sh, int spitch, int dw, int dh, int dpitch,
 }
 
 template <typename TIn, typename TOut>
-void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, const ResizeParams& R, const char* name)
+void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, const ResizeParams& R, const char* name, unsigned nz = 1)
 {
     int slot;
     timer_begin(c, name, s, slot);
     if (R.sstep != 1 || R.dstep != 1) {                      // one channel of an interleaved plane: the generic kernel addresses by element step
-        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4, nz);
         hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (R.dw == 2 * R.sw && R.dh == 2 * R.sh) {
-        dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4);
+        dim3 grid(((R.dw + 3) / 4 + 63) / 64, (R.dh + 3) / 4, nz);
         hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (2 * R.dw == 3 * R.sw && 2 * R.dh == 3 * R.sh) {
-        dim3 grid(((R.dw + 2) / 3 + 63) / 64, (R.dh + 3) / 4);
+        dim3 grid(((R.dw + 2) / 3 + 63) / 64, (R.dh + 3) / 4, nz);
         hipLaunchKernelGGL((k_resize3x2<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (R.dw == R.sw && R.dh == R.sh) {
-        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4, nz);
         hipLaunchKernelGGL((k_copy<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else {
-        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4);
+        dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4, nz);
         hipLaunchKernelGGL((k_resize<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     }
     timer_end(c, s, slot);
@@ -351,12 +356,23 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
 // (pixel rows [16 b, 16 b + 16)) reads HR rows up to 16 b + 16, i.e. filter tile rows <= b: the same ranges serve both kernels.
 struct NoRowsDone { void operator()(int, int) const {} };
 
+// frame batches: plane strides of this pass's launches (0 for a single frame); zs_out = stride of `out`'s planes
+void batch_strides(const raisr_hip_ctx* c, int pass, size_t zs_out, PassParams& P)
+{
+    if (c->zb_n <= 1) return;
+    const size_t plane = (size_t)c->passW[pass] * c->passH[pass];
+    P.zs_lr = (pass == 0 && c->lr0_alias) ? c->zb_in_stride : plane;
+    P.zs_hr = plane; P.zs_hash = plane; P.zs_out = zs_out;
+}
+
 template <typename TOut, typename RowsDone = NoRowsDone>
-void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems, int nchunks = 1, RowsDone done = RowsDone())
+void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems, int nchunks = 1, RowsDone done = RowsDone(), size_t zs_out = 0)
 {
     const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
+    batch_strides(c, pass, zs_out, P);
+    const unsigned nz = (unsigned)c->zb_n;
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
         constexpr int R = 4;        // rows per lane: 3..6 measure the same within noise, 8 is slower (occupancy)
@@ -475,8 +491,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                     hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 2>), dim3(gf.x, (unsigned)((H - 2 * kMargin + 7) / 8)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 else
 #endif
-                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
         } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
@@ -506,7 +522,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         done(0, H);
         return;
     }
-    dim3 gb((W + 63) / 64, (H + 15) / 16);
+    dim3 gb((W + 63) / 64, (H + 15) / 16, nz);
     timer_begin(c, "k_blend", s, slot);
     hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
@@ -536,15 +552,17 @@ Pass16 make_pass16(raisr_hip_ctx* c, int pass, int W)
 
 // one pass of the AVX512-FP16-exact pipeline (binary16 arithmetic)
 template <typename TOut>
-void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems)
+void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitch_elems, size_t zs_out = 0)
 {
     const void* lrp = (pass == 0 && c->lr0_alias) ? c->lr0_alias : c->d_lr[pass];    // two-pass mode 2: pass 1 reads the caller's plane in place
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
+    batch_strides(c, pass, zs_out, P);
+    const unsigned nz = (unsigned)c->zb_n;
     const Pass16 Q = make_pass16(c, pass, W);
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
-        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
+        dim3 gh((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16, c->fused ? nz : 1u);
         if (c->fused) {
             P.write_hash = c->keep_hash_plane;
             timer_begin(c, "k_hashfilter16", s, slot);
@@ -566,7 +584,7 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
         timer_end(c, s, slot);
         return;
     }
-    dim3 gb((W + 63) / 64, (H + 15) / 16);
+    dim3 gb((W + 63) / 64, (H + 15) / 16, nz);
     timer_begin(c, "k_blend16", s, slot);
     hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
     timer_end(c, s, slot);
@@ -1037,12 +1055,13 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     c->passH[0] = mode2 ? cfg->in_height : cfg->out_height;
     c->passW[1] = cfg->out_width; c->passH[1] = cfg->out_height;
     const size_t bps = cfg->bits == 8 ? 1 : 2;
+    const size_t cap = (size_t)(c->batch_cap < 1 ? 1 : c->batch_cap);     // frame batches: every plane exists `cap` times, back to back
     for (int p = 0; p < cfg->passes; p++) {
         const size_t n = (size_t)c->passW[p] * c->passH[p];
-        if (hipMalloc((void**)&c->d_lr[p], n * bps) != hipSuccess ||
-            hipMalloc((void**)&c->d_hash[p], n) != hipSuccess ||
+        if (hipMalloc((void**)&c->d_lr[p], cap * n * bps) != hipSuccess ||
+            hipMalloc((void**)&c->d_hash[p], cap * n) != hipSuccess ||
             hipMalloc((void**)&c->d_hash2[p], (size_t)c->passH[p] * 16) != hipSuccess ||
-            hipMalloc((void**)&c->d_hr[p], n * sizeof(float)) != hipSuccess) {
+            hipMalloc((void**)&c->d_hr[p], cap * n * sizeof(float)) != hipSuccess) {
             free_scratch(c);
             return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
         }
@@ -1065,11 +1084,11 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     }
     if (cfg->passes == 2) {
         // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
-        HIP_TRY(hipMemsetAsync(c->d_lr[1], 0, (size_t)c->passW[1] * c->passH[1] * bps, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_lr[1], 0, cap * (size_t)c->passW[1] * c->passH[1] * bps, c->stream));
         if (c->passW[0] != c->passW[1] || c->passH[0] != c->passH[1]) {
             const size_t n = (size_t)c->passW[0] * c->passH[0];
-            if (hipMalloc((void**)&c->d_mid, n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
-            HIP_TRY(hipMemsetAsync(c->d_mid, 0, n * bps, c->stream));
+            if (hipMalloc((void**)&c->d_mid, cap * n * bps) != hipSuccess) { free_scratch(c); return fail(RAISR_HIP_ENOMEM, "intermediate alloc"); }
+            HIP_TRY(hipMemsetAsync(c->d_mid, 0, cap * n * bps, c->stream));
         }
     }
     if (c->fast) {
@@ -1118,22 +1137,26 @@ static int process_y_device_impl(raisr_hip_ctx* c, const void* d_in, size_t in_p
     auto job = [&](auto tag) {
         using T = decltype(tag);
         ResizeParams R0 = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
+        const unsigned nz = (unsigned)c->zb_n;                  // frame batch: one launch per kernel, blockIdx.z = frame
+        const size_t plane0 = (size_t)c->passW[0] * c->passH[0], plane1 = (size_t)c->passW[1] * c->passH[1];
+        if (nz > 1) { R0.zs_src = c->zb_in_stride; R0.zs_dst = plane0; }
         // pass 1 at input size (two-pass mode 2, Raisr.cpp:960-975) on a tightly pitched plane: the kernels read it where it lies
         c->lr0_alias = (g.in_width == c->passW[0] && g.in_height == c->passH[0] && ipe == c->passW[0]) ? d_in : nullptr;
-        if (!c->lr0_alias) launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize");
+        if (!c->lr0_alias) launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize", nz);
         if (g.passes == 1) {
-            if (fp16) { run_pass16<T>(c, s, 0, d_out, ope); done(0, g.out_height); } else run_pass<T>(c, s, 0, d_out, ope, nchunks, done);
+            if (fp16) { run_pass16<T>(c, s, 0, d_out, ope, c->zb_out_stride); done(0, g.out_height); } else run_pass<T>(c, s, 0, d_out, ope, nchunks, done, c->zb_out_stride);
             return;
         }
         // pass 1 writes the integer intermediate (Raisr.cpp:927-934).  When both passes run at output size
         // (mode 1) the intermediate IS pass 2's LR plane; in mode 2 it is upscaled now (Raisr.cpp:945-975).
         void* mid = same ? c->d_lr[1] : c->d_mid;
-        if (fp16) run_pass16<T>(c, s, 0, mid, c->passW[0]); else run_pass<T>(c, s, 0, mid, c->passW[0]);
+        if (fp16) run_pass16<T>(c, s, 0, mid, c->passW[0], plane0); else run_pass<T>(c, s, 0, mid, c->passW[0], 1, NoRowsDone(), plane0);
         if (!same) {
             ResizeParams R1 = make_resize(c->passW[0], c->passH[0], c->passW[0], c->passW[1], c->passH[1], c->passW[1], g.tie_rule);
-            launch_resize<T, T>(c, s, c->d_mid, c->d_lr[1], R1, "k_resize");
+            if (nz > 1) { R1.zs_src = plane0; R1.zs_dst = plane1; }
+            launch_resize<T, T>(c, s, c->d_mid, c->d_lr[1], R1, "k_resize", nz);
         }
-        if (fp16) { run_pass16<T>(c, s, 1, d_out, ope); done(0, g.out_height); } else run_pass<T>(c, s, 1, d_out, ope, nchunks, done);
+        if (fp16) { run_pass16<T>(c, s, 1, d_out, ope, c->zb_out_stride); done(0, g.out_height); } else run_pass<T>(c, s, 1, d_out, ope, nchunks, done, c->zb_out_stride);
     };
     if (bps == 1) job(uint8_t{}); else job(uint16_t{});
     HIP_TRY(hipGetLastError());
@@ -1141,6 +1164,52 @@ static int process_y_device_impl(raisr_hip_ctx* c, const void* d_in, size_t in_p
 }
 
 extern "C" {
+
+// Frame batch (north_star: "frame batches"): n frames of the configured geometry through ONE launch per kernel, blockIdx.z =
+// frame, scratch planes n deep.  Small frames (540p, 720p) leave workgroup slots empty at the head and tail of every launch and
+// pay every launch's dispatch gap per frame; a batch pays them once.  One launch per kernel needs the frames equally spaced in
+// memory (plane i = plane 0 + i * stride, as in one allocation of n planes) and one of the production pipelines; anything else
+// -- and n == 1 -- runs frame by frame with the same results.
+int raisr_hip_process_y_device_batch(raisr_hip_ctx* c, int n, const void* const* d_in, size_t in_pitch,
+                                     void* const* d_out, size_t out_pitch, void* stream)
+{
+    if (!c || !d_in || !d_out || n < 1) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
+    for (int i = 0; i < n; i++) if (!d_in[i] || !d_out[i]) return fail(RAISR_HIP_EINVAL, "null plane in the batch");
+    const raisr_hip_config& g = c->cfg;
+    const int bps = g.bits == 8 ? 1 : 2;
+    const bool fp16 = g.hash_variant == RAISR_HIP_HASH_FP16;
+    bool one_launch = n > 1 && n <= RAISR_HIP_MAX_BATCH && c->fused && c->blending != RAISR_HIP_BLEND_RANDOMNESS &&
+                      (fp16 || (c->certify && !c->split && !c->fast));
+    ptrdiff_t si = 0, so = 0;
+    if (one_launch) {
+        si = (const char*)d_in[1] - (const char*)d_in[0]; so = (char*)d_out[1] - (char*)d_out[0];
+        for (int i = 2; i < n && one_launch; i++)
+            one_launch = ((const char*)d_in[i] - (const char*)d_in[i - 1]) == si && ((char*)d_out[i] - (char*)d_out[i - 1]) == so;
+        one_launch = one_launch && si > 0 && so > 0 && si % bps == 0 && so % bps == 0;
+    }
+    if (!one_launch) {
+        for (int i = 0; i < n; i++) {
+            const int rc = process_y_device_impl(c, d_in[i], in_pitch, d_out[i], out_pitch, stream, 1, NoRowsDone());
+            if (rc) return rc;
+        }
+        return RAISR_HIP_OK;
+    }
+    if (n > c->batch_cap) {                                     // grow the scratch planes: a re-configure with the same geometry
+        const raisr_hip_config cfg = c->cfg;
+        const int blending = c->blending;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+        c->batch_cap = n;
+        const int rc = raisr_hip_configure(c, &cfg);
+        c->blending = blending;
+        if (rc) return rc;
+    }
+    c->zb_n = n; c->zb_in_stride = (size_t)si / bps; c->zb_out_stride = (size_t)so / bps;
+    const int rc = process_y_device_impl(c, d_in[0], in_pitch, d_out[0], out_pitch, stream, 1, NoRowsDone());
+    c->zb_n = 1; c->zb_in_stride = c->zb_out_stride = 0;
+    return rc;
+}
 
 int raisr_hip_process_y_device(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch, void* stream)
 {

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
     int bx, by;
     xcd_tile(bx, by);
     by += P.tile_y0;
+    lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; out += blockIdx.z * P.zs_out;          // frame batches
     const int c0 = bx * TW, r0 = by * TH;
     {   // wave w sweeps columns [0,64) of tile rows w, w+4, ...; the two right-hand halo columns go to the first 36 threads.
         // All LR and HR loads of a thread are in flight before the first LDS write.

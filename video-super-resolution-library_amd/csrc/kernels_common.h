@@ -38,6 +38,9 @@ struct PassParams {
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
     const uint32_t* asym;        // symmetric filter stage (filter_phase<.., SYM>): bitmap [32 words] of the (bucket * pixel_types + type) bank rows
                                  // that are NOT palindromic (f[k] != f[120-k] somewhere), or null when every row is
+    // frame batches (raisr_hip_process_y_device_batch): blockIdx.z = frame; plane f of a batch starts f * zs_* ELEMENTS after plane 0
+    // (all 0 for a single frame).  Only the production kernels (k_hashfilter_ac, k_blend, k_hashfilter16, k_blend16) read these.
+    size_t zs_lr, zs_hr, zs_hash, zs_out;
     int tile_y0;                 // first tile row of this launch (k_hashfilter_ac / k_blend launched on a range of tile rows: the host
                                  // path pipelines the download of finished rows with the kernels of the next rows)
 };

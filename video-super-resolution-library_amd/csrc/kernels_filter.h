@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_has
     int bx, by;
     xcd_tile(bx, by);
     by += P.tile_y0;
+    lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
     hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 

@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
+    lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
     for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
@@ -594,6 +595,7 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
     xcd_tile(bx, by);
+    lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; out += blockIdx.z * P.zs_out;          // frame batches
     const int c0 = bx * TW, r0 = by * TH;
     {
         constexpr int NM = (LH + 3) / 4, REM = LW - 64;

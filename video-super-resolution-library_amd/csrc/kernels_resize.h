@@ -16,6 +16,7 @@ struct ResizeParams {
                                  // two-channel plane: the UV plane of NV12 / P010); pitches stay in samples of the container
     int narrow;                  // 1: the 32-bit path of k_resize is exact for this geometry (make_resize)
     float rdenx, rdeny, rden2;   // 1 / (2 Dx), 1 / (2 Dy), 1 / (2 * 2 Dx * 2 Dy)
+    size_t zs_src, zs_dst;       // frame batches: blockIdx.z = frame, planes zs_* elements apart (0 for a single plane)
 };
 
 __device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0, int& i1, int& f)
@@ -56,6 +57,7 @@ __device__ __forceinline__ void axis_tap_small(int d, int S, int D, float rden, 
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
+    src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= R.dw || y >= R.dh) return;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
+    src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     int bx, by;
     xcd_tile(bx, by);                                         // vertically adjacent blocks share input rows: keep them on one XCD
     const int t = bx * 64 + (threadIdx.x & 63);               // group of 4 output columns
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, T
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
+    src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     int bx, by;
     xcd_tile(bx, by);
     const int m = bx * 64 + (threadIdx.x & 63);               // group of 3 output columns
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, 
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
+    src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < R.dw && y < R.dh) dst[(size_t)y * R.dpitch + x] = (TOut)src[(size_t)y * R.spitch + x];

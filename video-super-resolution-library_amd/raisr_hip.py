@@ -91,6 +91,9 @@ def lib():
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_set_model_blob_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_configure.argtypes = [ctypes.c_void_p, ctypes.POINTER(RaisrHipConfig)]
+        if os.environ.get("RAISR_HIP_LIB") is None or hasattr(L, "raisr_hip_process_y_device_batch"):
+            L.raisr_hip_process_y_device_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                            ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_process_y_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_resize_plane_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
@@ -131,7 +134,8 @@ def lib():
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        L.raisr_hip_debug_fold16_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        if os.environ.get("RAISR_HIP_LIB") is None or hasattr(L, "raisr_hip_debug_fold16_check"):      # (an older A/B build may lack the newest hooks)
+            L.raisr_hip_debug_fold16_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_use_streams.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -365,6 +369,16 @@ class RaisrDevice:
 
     def process_y(self, d_in, in_pitch, d_out, out_pitch, stream=None):
         _check(lib().raisr_hip_process_y_device(self._h, d_in, in_pitch, d_out, out_pitch, stream), "raisr_hip_process_y_device")
+
+    def process_y_batch(self, d_in_list, in_pitch, d_out_list, out_pitch, stream=None):
+        """n device-resident frames through one launch per kernel (equally spaced planes; otherwise frame by frame)"""
+        n = len(d_in_list)
+        key = (tuple(d_in_list), tuple(d_out_list))
+        cache = self.__dict__.setdefault("_batch_tabs", {})
+        if key not in cache:                                   # pointer tables are reused by loops that resubmit the same planes
+            cache[key] = ((ctypes.c_void_p * n)(*d_in_list), (ctypes.c_void_p * n)(*d_out_list))
+        a_in, a_out = cache[key]
+        _check(lib().raisr_hip_process_y_device_batch(self._h, n, a_in, in_pitch, a_out, out_pitch, stream), "raisr_hip_process_y_device_batch")
 
     def resize_plane(self, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream=None):
         _check(lib().raisr_hip_resize_plane_device(self._h, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream),
