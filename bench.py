@@ -28,8 +28,8 @@ and, at N = 1 (outside the timed region of `value`, never mixed into it):
   configs      -- BASELINE.json's C1, C3, C4, C5 next to C2: fps, isolated kernel times, both rooflines, self-check
   frame_kinds  -- C2 on natural / random / constant / 1-px-checkerboard frames (throughput depends on content through the
                   share of pixels that take the exact hash path)
-  fast_mode    -- the opt-in, NOT bit-exact matrix-core filter stage (raisr_hip_set_fast(2)): the same loop, with its
-                  distance from the oracle beside it.  Never the headline.
+  (the matrix-core "fast mode" of rounds 2-3 left the product in round 4: it measured slower than the exact path; a development
+   build keeps it, docs/EXPERIMENTS.md)
 At N > 1 the line carries `stream` only: every rank streaming host-resident frames through its pinned ring at the same
 time (PCIe / host-memory contention next to the HBM-resident headline).
 """
@@ -802,19 +802,6 @@ def main():
                     out["what"] = f"C2, {args.extra_frames} frames per kind, {args.lanes} lanes; `value` of this line is the `{args.frame_kind}` kind on {frames_total} frames"
                     return out
                 leg("frame_kinds", kinds_leg)
-            if wl.pixel_types == 4 and wl.bits <= 10 and wl.asm != 5 and hasattr(R.RaisrDevice, "set_fast"):
-                def fast_leg():
-                    # NOT a parity path and never the headline: the opt-in matrix-core filter stage, same loop as `value`
-                    n = args.extra_frames
-                    dtf, _, lf, _, _ = device_loop(R, torch, wl, gpu, blobs, args.lanes, wl.frames(args.frame_kind, range(8)), n, 1, 1, fence, False, fast=2)
-                    for d in lf:
-                        d.close()
-                    par = parity_leg(R, wl, gpu, blobs, args.frame_kind, fast=2)
-                    return {"value": round(wl.out_w * wl.out_h * n / dtf / 1e6, 2), "unit": "MP/s", "fps": round(n / dtf, 2), "frames": n,
-                            "bit_exact": False, "differing_pixels": par["mismatches"], "max_abs_diff": par["max_abs_diff"], "psnr_vs_oracle": par["psnr"],
-                            "what": "raisr_hip_set_fast(2): approximate-tensor buckets without the exact re-hash + 121-tap filter on the matrix "
-                                    "cores (binary16 coefficients); off by default"}
-                leg("fast_mode", fast_leg)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:

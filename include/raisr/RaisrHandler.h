@@ -49,12 +49,13 @@ RNLERRORTYPE RNLHandler_Deinit(void);
  * Asynchronous frames -- an EXTENSION of the reference's surface (its Process is synchronous, Raisr.cpp:1294-1397): what a
  * filter with frame queuing (ffmpeg/vf_raisr_hip.diff, option async=N) uses to keep N frames in flight so that uploads, kernels
  * and downloads of neighbouring frames overlap.  Same validation, same bits as Process.
- *   SetAsyncDepth(N)   after Init, before the first Submit; N = 0 releases the ring; at most 4 lanes are built
+ *   SetAsyncDepth(N)   after Init, before the first Submit; N = 0 releases the ring; N <= 4 (RNLErrorBadParameter above)
  *   Submit(...)        enqueue one frame and return; RNLErrorInsufficientResources = N frames already in flight (Collect first).
  *                      Every plane must stay valid and untouched until the frame's Collect returns.
  *   Collect()          wait for the OLDEST submitted frame; its output planes are complete on return
  *   FramesInFlight()   submitted and not yet collected
- * Deinit and SetRes wait for the frames in flight.  Not available with asm = HIPExternal (device frames are stream-ordered).
+ * Deinit waits for the frames in flight and drops them; SetRes refuses (RNLErrorBadParameter) while frames are in flight:
+ * collect them first.  Not available with asm = HIPExternal (device frames are stream-ordered).
  */
 RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth);
 RNLERRORTYPE RNLHandler_Submit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,

@@ -196,7 +196,8 @@ int  raisr_hip_set_chunks(raisr_hip_ctx *ctx, int n);               /* host-plan
 int  raisr_hip_set_after(raisr_hip_ctx *ctx, raisr_hip_ctx *prev);   /* bands of one frame: ctx's Y kernels (host-plane entry) start after prev's */
 
 typedef struct raisr_hip_stream raisr_hip_stream;
-int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..16; at most 4 lanes are built (one stream each) */
+#define RAISR_HIP_STREAM_MAX_DEPTH 4                                                    /* frames in flight per ring: more never measured faster */
+int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..RAISR_HIP_STREAM_MAX_DEPTH, else RAISR_HIP_EINVAL */
 void raisr_hip_stream_destroy(raisr_hip_stream *s);
 int  raisr_hip_stream_depth(const raisr_hip_stream *s);
 int  raisr_hip_stream_set_model(raisr_hip_stream *s, int pass_index, const float *bank, int hashkeys, int pixel_types,
@@ -220,13 +221,13 @@ int  raisr_hip_host_register(void *p, size_t bytes); /* page-lock memory the cal
 int  raisr_hip_host_unregister(void *p);
 int  raisr_hip_host_is_page_locked(const void *p); /* 1: p lies in memory from raisr_hip_host_alloc / hipHostMalloc or in a registered range; 0: pageable (or not host memory) */
 
-/* NON-bit-exact fast mode (north_star's MFMA question; off by default, RAISR_HIP_FAST=1 turns it on at
- * create time).  The buckets stay exact (certified hash stage); the 121-tap dot product of DotProdPatch_AVX512_32f
- * (Raisr_AVX512.cpp:134-149) runs on the matrix cores with binary16 coefficients and the MFMA's own fp32 summation order,
- * and the AVX2 re-hash of the tail columns (Raisr.cpp:1247-1250) is not applied.  Output differs from the exact mode by
- * rounding noise (measured in DESIGN.md s5; tests/test_gpu_fast_mode.py bounds it).  Supported: ratio 2, 8/10-bit content,
- * asm avx2/avx512; anything else is refused here (configured context) or by raisr_hip_configure.  Replaces nothing in the
- * reference, which has no such mode. */
+/* NON-bit-exact fast mode (north_star's MFMA question): DEVELOPMENT BUILDS ONLY since round 4.  The product
+ * library refuses every level > 0 (and RAISR_HIP_FAST > 0 at create time) with RAISR_HIP_EINVAL: the matrix-core filter stage
+ * measured slower than the exact path (docs/EXPERIMENTS.md), so north_star's question is answered "no".  In a build with
+ * -DRAISR_HIP_DEV: buckets exact (level 1) or approximate without the exact re-hash (level 2), the 121-tap dot product of
+ * DotProdPatch_AVX512_32f (Raisr_AVX512.cpp:134-149) on the matrix cores with binary16 coefficients; ratio 2, 8/10-bit, asm
+ * avx2/avx512 only; bounded by tests/test_gpu_fast_mode.py.  The entry points stay in the ABI so that callers written against
+ * rounds 2-3 link. */
 int raisr_hip_set_fast(raisr_hip_ctx *ctx, int on);
 int raisr_hip_get_fast(const raisr_hip_ctx *ctx);
 

@@ -10,8 +10,12 @@ import pytest
 
 from common import folder, oracle_y, dtype_for
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "video-super-resolution-library_amd", "_exp", "libraisr_dev.so")
+# Round 4 took the fast mode out of the product library (it measured slower than the exact path: docs/EXPERIMENTS.md).  The quality
+# bounds below run against a DEVELOPMENT build only (scripts/build_exp.sh dev -DRAISR_HIP_DEV; RAISR_HIP_LIB points at it and
+# RAISR_HIP_DEV_BUILD=1 says so) -- tests/test_gpu_product_refuses_fast_mode.py starts them in a subprocess when that build exists.
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RAISR_HIP_DEV_BUILD") != "1", reason="fast mode exists in development builds only")]
 
 CASES = [  # (id, folder, ratio, bits, passes, mode, asm, full)
     ("2x_8b_avx512", "filters_2x/filters_highres", (2, 1), 8, 1, 1, 2, False),

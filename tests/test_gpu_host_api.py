@@ -331,7 +331,7 @@ def test_async_submit_collect_frames_equal_the_oracle_in_order(bits, asm, passes
         assert R.RNLHandler_SetRes((ys[0], us[0], vs[0]), outs[0]) == 0
         assert R.RNLHandler_Submit((ys[0], us[0], vs[0]), outs[0]) == R.RNLErrorBadParameter          # no ring asked for
         assert R.RNLHandler_Collect() == R.RNLErrorBadParameter
-        assert R.RNLHandler_SetAsyncDepth(17) == R.RNLErrorBadParameter
+        assert R.RNLHandler_SetAsyncDepth(5) == R.RNLErrorBadParameter                                # more than the ring builds: refused, not clamped
         assert R.RNLHandler_SetAsyncDepth(depth) == 0
         built = min(depth, 4)
         collected = 0
@@ -349,6 +349,7 @@ def test_async_submit_collect_frames_equal_the_oracle_in_order(bits, asm, passes
                 collect()
             assert R.RNLHandler_Submit((ys[i], us[i], vs[i]), outs[i]) == 0
         assert R.RNLHandler_SetAsyncDepth(0) == R.RNLErrorBadParameter                                # frames in flight
+        assert R.RNLHandler_SetRes((ys[0], us[0], vs[0]), outs[0]) == R.RNLErrorBadParameter          # ... are not dropped by a SetRes either
         while R.RNLHandler_FramesInFlight():
             collect()
         assert collected == n and R.RNLHandler_Collect() == R.RNLErrorBadParameter

@@ -57,14 +57,23 @@ namespace {
 #include "kernels_hash_certify.h"    // approx_hash, tensor_ac, hash_phase_ac
 #include "kernels_fp16.h"            // binary16 pipeline: k_hashfilter16, k_hash16, k_filter16, k_blend16
 #include "kernels_filter.h"          // filter_phase, k_filter, k_hashfilter, k_hashfilter_ac
+#ifdef RAISR_HIP_DEV
+#include "kernels_experiments.h"     // persistent-grid variant of k_hashfilter_ac (-DRAISR_EXP_PERSIST)
+#endif
 #include "kernels_split.h"           // k_hash_ac, k_fix_*, k_filter_lds16
+#ifdef RAISR_HIP_DEV                 /* development builds only: measured slower than the exact path (docs/EXPERIMENTS.md) */
 #include "kernels_fast.h"            // k_filter_mfma
+#endif
 #include "kernels_blend.h"           // k_blend, k_blend_rand
 
 // ------------------------------------------------------------------------------------------------
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+// The matrix-core filter stage (north_star's MFMA question) is answered "no": with exact buckets it equals the exact path's speed,
+// and since round 4 it is slower (docs/EXPERIMENTS.md).  It stays in development builds as a measurement.
+[[maybe_unused]] const char* const kNoFastMode = "the NON-bit-exact fast mode (matrix-core filter stage) is not part of the product build: it is slower than the "
+                                "exact path; a development build (-DRAISR_HIP_DEV) keeps it for measurements";
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -356,6 +365,41 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
 // (pixel rows [16 b, 16 b + 16)) reads HR rows up to 16 b + 16, i.e. filter tile rows <= b: the same ranges serve both kernels.
 struct NoRowsDone { void operator()(int, int) const {} };
 
+#ifdef RAISR_HIP_DEV
+// development builds: profiling variants of the fused kernel's launch (parts of the kernel, rejected experiments: docs/EXPERIMENTS.md);
+// returns true when one of them took the launch
+template <typename TOut>
+bool launch_dev_variant(raisr_hip_ctx* c, hipStream_t s, int pass, const void* lrp, PassParams& P, dim3 gf, int H, bool sym)
+{
+    static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
+    if (part == 2 && getenv("RAISR_HIP_AC_PATTERN")) P.cert_check = atoi(getenv("RAISR_HIP_AC_PATTERN"));
+    if (part == 1) { hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]); return true; }
+    if (part == 2) {
+        if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+        else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+        return true;
+    }
+#ifdef RAISR_EXP_PERSIST
+    if (getenv("RAISR_HIP_PERSIST") || getenv("RAISR_HIP_PERSIST_DYN")) {
+        const bool dyn = !getenv("RAISR_HIP_PERSIST");
+        static unsigned* ctr = nullptr;         // experiment only: one set of counters, one lane
+        if (dyn) { if (!ctr) (void)hipMalloc((void**)&ctr, 16 * sizeof(unsigned)); (void)hipMemsetAsync(ctr, 0, 16 * sizeof(unsigned), s); }
+        const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv(dyn ? "RAISR_HIP_PERSIST_DYN" : "RAISR_HIP_PERSIST")));
+        hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
+                           c->n_cus, (!dyn && getenv("RAISR_HIP_PERSIST_SKEW")) ? atoi(getenv("RAISR_HIP_PERSIST_SKEW")) : 0, dyn ? ctr : (unsigned*)nullptr);
+        return true;
+    }
+#endif
+#ifdef RAISR_EXP_TILE8
+    if (getenv("RAISR_HIP_TILE8")) {
+        hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 2>), dim3(gf.x, (unsigned)((H - 2 * kMargin + 7) / 8)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+        return true;
+    }
+#endif
+    return false;
+}
+#endif
+
 // frame batches: plane strides of this pass's launches (0 for a single frame); zs_out = stride of `out`'s planes
 void batch_strides(const raisr_hip_ctx* c, int pass, size_t zs_out, PassParams& P)
 {
@@ -405,6 +449,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 hipLaunchKernelGGL((k_fix_dense<TOut, true>), dim3(nd), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, F, c->d_hash[pass], c->d_hash2[pass]);
             timer_end(c, s, slot);
             }
+#ifdef RAISR_HIP_DEV
             if (c->fast && c->model[pass].bank_mfma) {             // the panels are allocated by configure / set_fast (errors reported there)
                 ModelDev& m = c->model[pass];
                 if (!m.bank_mfma_valid) {
@@ -423,6 +468,9 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                     hipLaunchKernelGGL((k_filter_mfma<TOut>), gm, dim3(kMfThreads), kMfLds, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, (const uint4*)m.bank_mfma, c->d_hr[pass], F.counters);
                     timer_end(c, s, slot);
                 }
+#else
+            if (0) {
+#endif
             } else if (c->lds_filter && c->cfg.bits <= 10) {      // samples above 10 bits are not exact in binary16: k_filter
                 const bool sp2 = P.pixel_types == 4;
                 const int wh = sp2 ? 41 : 26;
@@ -461,35 +509,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
             timer_begin(c, "k_hashfilter_ac", s, slot);
-#ifdef RAISR_HIP_DEV                                                  /* profiling aid of a development build: hash stage only / filter stage only */
-            static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
-            if (part == 2 && getenv("RAISR_HIP_AC_PATTERN")) P.cert_check = atoi(getenv("RAISR_HIP_AC_PATTERN"));
-            if (part == 1)
-                hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-            else if (part == 2)
-                { if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                  else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]); }
-            else
-#endif
-#ifdef RAISR_EXP_PERSIST
-                if (getenv("RAISR_HIP_PERSIST")) {
-                    const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST")));
-                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
-                                       c->n_cus, getenv("RAISR_HIP_PERSIST_SKEW") ? atoi(getenv("RAISR_HIP_PERSIST_SKEW")) : 0,
-                                       (unsigned*)nullptr);
-                } else if (getenv("RAISR_HIP_PERSIST_DYN")) {
-                    static unsigned* ctr = nullptr;         // experiment only: one set of counters, one lane
-                    if (!ctr) (void)hipMalloc((void**)&ctr, 16 * sizeof(unsigned));
-                    (void)hipMemsetAsync(ctr, 0, 16 * sizeof(unsigned), s);
-                    const unsigned nt = gf.x * gf.y, per = (unsigned)(c->n_cus * atoi(getenv("RAISR_HIP_PERSIST_DYN")));
-                    hipLaunchKernelGGL((k_hashfilter_acp<TOut>), dim3(nt < per ? nt : per), dim3(256), 0, s, (const TOut*)c->d_lr[pass], P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (int)gf.x, (int)gf.y,
-                                       c->n_cus, 0, ctr);
-                } else
-#endif
-#ifdef RAISR_EXP_TILE8
-                if (getenv("RAISR_HIP_TILE8"))
-                    hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 2>), dim3(gf.x, (unsigned)((H - 2 * kMargin + 7) / 8)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                else
+#ifdef RAISR_HIP_DEV
+            if (launch_dev_variant<TOut>(c, s, pass, lrp, P, gf, H, sym)) {} else
 #endif
                 if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
@@ -695,7 +716,11 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
+#ifdef RAISR_HIP_DEV
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
+#else
+    if (const char* e = getenv("RAISR_HIP_FAST")) if (atoi(e) > 0) return fail(RAISR_HIP_EINVAL, kNoFastMode);           // asked for, not available: say so
+#endif
     if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_CHUNKS")) { const int v = atoi(e); c->chunks = v < 1 ? 1 : (v > 8 ? 8 : v); }
@@ -707,8 +732,10 @@ static int create_impl(raisr_hip_ctx* c)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
 #endif
+#ifdef RAISR_HIP_DEV
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
+#endif
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -989,6 +1016,7 @@ static bool fast_mode_supported(const raisr_hip_config* cfg)
     return cfg->use_pixel_type && cfg->bits <= 10 && cfg->hash_variant != RAISR_HIP_HASH_FP16;
 }
 
+#ifdef RAISR_HIP_DEV
 // B panels of k_filter_mfma for every pass in use (590 KB each); filled on the stream by the first frame that needs them
 static int alloc_fast_banks(raisr_hip_ctx* c, int passes)
 {
@@ -1002,8 +1030,14 @@ static int alloc_fast_banks(raisr_hip_ctx* c, int passes)
     return RAISR_HIP_OK;
 }
 
+#else
+static int alloc_fast_banks(raisr_hip_ctx*, int) { return RAISR_HIP_OK; }
+#endif
 int raisr_hip_set_fast(raisr_hip_ctx* c, int on)
 {
+#ifndef RAISR_HIP_DEV
+    if (c && on > 0) return fail(RAISR_HIP_EINVAL, kNoFastMode);
+#endif
     if (!c) return fail(RAISR_HIP_EINVAL, "null argument");
     if (on && c->configured && !fast_mode_supported(&c->cfg))
         return fail(RAISR_HIP_EINVAL, "fast mode (matrix-core filter stage) supports ratio 2, 8/10-bit content and the fp32 flavours only");
@@ -1379,12 +1413,18 @@ static hipError_t copy_plane(void* dst, size_t dpitch, const void* src, size_t s
 
 // One plane (or row range) between the caller's host memory and the device.  Page-locked host memory: an asynchronous copy.
 // Pageable host memory: through the context's bounce memory (host_copy.h) -- packed now (upload) or unpacked when the frame is
-// synchronised (download).  RAISR_HIP_BOUNCE=0 hands pageable memory to the runtime as rounds 1-2 did (A/B measurements only).
+// synchronised (download).  The library never hands pageable memory to a HIP copy call: a sporadic GPU page fault of round 3
+//  occurred only on the runtime's own pageable-copy paths.  A development build (-DRAISR_HIP_DEV) keeps
+// RAISR_HIP_BOUNCE=0 -- pageable planes straight to the runtime, as rounds 1-2 did -- for A/B measurements and fault hunting.
 static hipError_t host_copy(raisr_hip_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes, size_t rows,
                             hipMemcpyKind kind, hipStream_t s)
 {
     if (!rows || !row_bytes) return hipSuccess;
+#ifdef RAISR_HIP_DEV
     static const bool bounce_on = !(getenv("RAISR_HIP_BOUNCE") && atoi(getenv("RAISR_HIP_BOUNCE")) == 0);
+#else
+    constexpr bool bounce_on = true;
+#endif
     const bool h2d = kind == hipMemcpyHostToDevice;
     const void* hp = h2d ? src : dst;
     const size_t hpitch = h2d ? spitch : dpitch;
@@ -1393,7 +1433,13 @@ static hipError_t host_copy(raisr_hip_ctx* c, void* dst, size_t dpitch, const vo
     if (!b) return hipErrorOutOfMemory;
     if (h2d) {
         RowCopyPool::get().copy(b, row_bytes, (const char*)src, spitch, row_bytes, rows);
-        return copy_plane(dst, dpitch, b, row_bytes, row_bytes, rows, kind, s);
+        hipError_t e = copy_plane(dst, dpitch, b, row_bytes, row_bytes, rows, kind, s);
+        if (e != hipSuccess) return e;
+        hipEvent_t ev = c->bounce.next_event();                // the bounce memory is reusable once this copy has been executed
+        if (!ev) return hipErrorOutOfMemory;
+        e = hipEventRecord(ev, s);
+        if (e == hipSuccess) c->bounce.uploads.push_back(ev);
+        return e;
     }
     hipError_t e = copy_plane(b, row_bytes, src, spitch, row_bytes, rows, kind, s);
     if (e != hipSuccess) return e;

@@ -132,18 +132,23 @@ struct HostBounce {
     size_t bytes = 0, used = 0, want = 0;
     struct Unpack { char* dst; size_t dpitch; const char* src; size_t row_bytes, rows; hipEvent_t ev; };
     std::vector<Unpack> unpack;              // downloads whose bytes still sit in the bounce memory
-    std::vector<hipEvent_t> events;          // one per download of a frame, re-used frame after frame
+    std::vector<hipEvent_t> events;          // one per bounced copy of a frame (uploads and downloads), re-used frame after frame
     size_t ev_used = 0;
+    std::vector<hipEvent_t> uploads;         // events behind this frame's bounced uploads: the DMA engine may still be reading the memory
 
     // first and last byte in the runtime's table of page-locked memory
     static bool page_locked(const void* p, size_t n)
     {
         return n && raisr_hip_host_is_page_locked(p) && raisr_hip_host_is_page_locked((const char*)p + n - 1);
     }
-    // a new frame starts: it may need up to `need` bytes; nothing of the previous frame may be pending (the caller synchronised).
+    // a new frame starts: it may need up to `need` bytes.  The previous frame's downloads have been unpacked by the caller
+    // (finish()); its UPLOADS are waited for here -- a second asynchronous frame on the same context without a synchronise in
+    // between would otherwise repack rows into memory the copy engine is still reading (or free it in take()).
     // The memory itself is allocated by the first plane that turns out to be pageable.
     void begin_frame(size_t need)
     {
+        for (hipEvent_t e : uploads) (void)hipEventSynchronize(e);
+        uploads.clear();
         used = 0;
         ev_used = 0;
         want = need;
@@ -185,6 +190,8 @@ struct HostBounce {
     }
     void release()
     {
+        for (hipEvent_t e : uploads) (void)hipEventSynchronize(e);
+        uploads.clear();
         unpack.clear();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();

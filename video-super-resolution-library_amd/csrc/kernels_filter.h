@@ -49,10 +49,6 @@ __device__ __forceinline__ float tree16(float acc)
 // their pixels are redone with the full eight loads after the row's main loop.
 __device__ __forceinline__ float partner_xchg(float v)      // lane p of every row of 16 receives lane (8 - p) & 15
 {
-#ifdef RAISR_EXP_SYM_BPERM                                  // experiment: through the LDS crossbar instead of two VALU moves
-    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) | ((8u - lane) & 15u)) * 4u), __float_as_int(v)));
-#endif
     // (every lane of a row has a source lane: `old` is never used, so it is the source itself and no register is zeroed for it)
     const int x = __float_as_int(v);
     int t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, true);                      // row_mirror: t[p] = v[15 - p]
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // k_hashfilter_ac: k_hashfilter with the certified hash stage (hash_phase_ac) -- the production kernel of the fp32
 // numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
 // pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
-// PART (profiling aid, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only (bucket 0).
+// PART (development builds, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only.
 // Four workgroups per CU (16 waves): 128 VGPRs and 40 384 B of LDS (4 x 40 960 = the CU's 160 KB).  Round 2 ran three (144 VGPRs,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
@@ -331,12 +327,13 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         }
     }
     __syncthreads();
-    if (PART != 2) hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
-    else {
-        // P.cert_check doubles as the bucket pattern of this profiling aid: 0 = every row of the bank, 1 = one row, 2 = sixteen rows
+#ifdef RAISR_HIP_DEV
+    if (PART == 2) {     // profiling aid: filter stage only; P.cert_check doubles as the bucket pattern (0 = every row of the bank, 1 = one row, 2 = sixteen rows)
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
         __syncthreads();
-    }
+    } else
+#endif
+    hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
     if (P.write_hash) {
         const int c = c0 + lane;
 #pragma unroll
@@ -351,21 +348,12 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
-#ifdef RAISR_EXP_PERSIST_PRIO
-    __builtin_amdgcn_s_setprio(3);                           // experiment: filter-stage waves first (what oldest-first arbitration gives the non-persistent grid)
-#endif
     if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
-#ifdef RAISR_EXP_PERSIST_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
-#ifndef RAISR_EXP_TILE8_WGS
-#define RAISR_EXP_TILE8_WGS 6
-#endif
 template <typename T, int PART = 0, int RPW = 4, bool SYM = false>
-__global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+__global__ __launch_bounds__(256, RPW == 4 ? 4 : 6) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
     constexpr int TW = 64, TH = 4 * RPW;
@@ -387,61 +375,5 @@ __global__ __launch_bounds__(256, RPW == 4 ? 4 : RAISR_EXP_TILE8_WGS) void k_has
     hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 
-#ifdef RAISR_EXP_PERSIST
-// Experiment: the same tile routine in a persistent grid (4 workgroups per CU walk the tiles in XCD-aware order).
-#ifndef RAISR_EXP_PERSIST_WGS
-#define RAISR_EXP_PERSIST_WGS 4
-#endif
-template <typename T>
-__global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
-                                                           uint8_t* __restrict__ hash_out, float* __restrict__ hr, int tiles_x, int tiles_y,
-                                                           int ncus, int skew_ticks, unsigned* __restrict__ tile_ctr)
-{
-    constexpr int TW = 64, TH = 16;
-    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
-    __shared__ float sL[LH * LW];
-    using GT = typename GradOf<T>::type;
-    __shared__ GT sG[GH * GW_];
-    __shared__ typename FVec<4>::type sV[3 * 4 * GW_];
-    uint2* sTab = reinterpret_cast<uint2*>(sV);
-    __shared__ uint8_t sH[TH * TW];
-    __shared__ uint8_t sH2[TH * TW];
-    __shared__ uint16_t sList[kListMax];
-    __shared__ unsigned sCnt[3];
-    const unsigned ntiles = (unsigned)(tiles_x * tiles_y);
-    if (skew_ticks > 0) {                                  // de-phase the workgroups that share a CU (k-th workgroup of a CU starts k * skew later)
-        const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x / (unsigned)ncus) * (unsigned)skew_ticks);
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-    __shared__ unsigned sTile;
-    const unsigned xcd = blockIdx.x & 7u, n8 = ntiles & ~7u, per = n8 >> 3;
-#pragma unroll 1
-    for (unsigned t = blockIdx.x; ; t += gridDim.x) {
-        int bx, by;
-        if (tile_ctr) {                                    // dynamic: the next tile of this XCD's strip (one counter per XCD)
-            if (threadIdx.x == 0) sTile = atomicAdd(&tile_ctr[xcd], 1u);
-            __syncthreads();
-            const unsigned j = sTile;
-            unsigned u;
-            if (j < per) u = xcd * per + j;
-            else if (j == per && n8 + xcd < ntiles) u = n8 + xcd;
-            else break;
-            by = (int)(u / (unsigned)tiles_x); bx = (int)(u - (unsigned)by * (unsigned)tiles_x);
-        } else {
-            if (t >= ntiles) break;
-            xcd_tile_of(t, (unsigned)tiles_x, ntiles, bx, by);
-        }
-        unsigned tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));                      // opaque per tile: keeps the tile routine's lane-dependent set-up inside the loop
-        __builtin_assume(tid < 256u);                      // (hoisted, it costs 52 spilled registers per lane)
-        hashfilter_ac_tile<T, 0, LW, LH, GW_, GH, GT>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, tid);
-#ifdef RAISR_EXP_PERSIST_LDSBAR
-        lds_barrier();                                     // every wave is done with this tile's LDS (the HR stores stay in flight)
-#else
-        __syncthreads();                                   // every wave is done with this tile's LDS
-#endif
-    }
-}
-#endif
 
 

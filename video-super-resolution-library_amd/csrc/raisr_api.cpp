@@ -471,6 +471,12 @@ RNLERRORTYPE RNLSetRes(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
     cfg.use_pixel_type = G.ratio == 2.0f ? 1 : 0;     // gUsePixelType, Raisr.cpp:1477-1480
     cfg.tie_rule = RAISR_HIP_TIE_HALF_UP;
 
+    // frames submitted and not yet collected would be lost with the ring: the caller collects first (the reference has no frames
+    // in flight; this keeps Submit / Collect pairs intact)
+    if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) {
+        std::cout << "[RAISR ERROR] RNLSetRes with " << raisr_hip_stream_in_flight(G.ring) << " frame(s) in flight: collect them first" << std::endl;
+        return RNLErrorBadParameter;
+    }
     G.cfg = cfg;
     // band plan: luma with the pass count's padding, chroma (cheap upscale only) with its own
     dropRing();
@@ -653,7 +659,7 @@ void RNLHostFree(void *p) { raisr_hip_host_free(p); }
 // every plane valid and untouched between a frame's Submit and its Collect.
 RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth)
 {
-    if (depth > 16) return RNLErrorBadParameter;
+    if (depth > RAISR_HIP_STREAM_MAX_DEPTH) return RNLErrorBadParameter;           // what the ring builds; a larger request is refused, not clamped
     if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) return RNLErrorBadParameter;      // collect first
     dropRing();
     G.asyncDepth = depth;
@@ -670,6 +676,7 @@ static RNLERRORTYPE checkFrame(VideoDataType *const pl[6])
             if (pl[i]->width != pl[i - 1]->width || pl[i]->height != pl[i - 1]->height) return RNLErrorBadParameter;
         } else if (pl[i]->width != G.geo[i][0] || pl[i]->height != G.geo[i][1]) return RNLErrorBadParameter;
         if ((uint64_t)pl[i]->step < (uint64_t)pl[i]->width * bps) return RNLErrorBadParameter;
+        if (pl[i]->bitShift & RAISR_HIP_INTERLEAVED2) return RNLErrorBadParameter;     // interleaved chroma: device frames only (RNLProcess, asm = HIPExternal)
     }
     return RNLErrorNone;
 }

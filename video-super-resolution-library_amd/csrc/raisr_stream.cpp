@@ -41,8 +41,7 @@ extern "C" {
 
 int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
 {
-    if (!out || depth < 1 || depth > 16) return RAISR_HIP_EINVAL;
-    if (depth > 4) depth = 4;                                           // see raisr_hip_stream::comp; raisr_hip_stream_depth() reports what was built
+    if (!out || depth < 1 || depth > RAISR_HIP_STREAM_MAX_DEPTH) return RAISR_HIP_EINVAL;   // more lanes than that were never faster (see raisr_hip_stream::comp): refused, not clamped
     raisr_hip_stream* s = new raisr_hip_stream();
     s->device = device_index;
     for (int i = 0; i < depth; i++) {
