@@ -43,7 +43,7 @@ def test_bench_plain_contract_fields():
     # the side legs: 2-pass (north_star's target config), host->host through the plugin API, parity vs the oracle
     assert j["c3_2pass"]["value"] > 0 and j["c3_2pass"]["unit"] == "MP/s"
     assert j["config"]["mode"] == "exact"
-    assert j["fast_mode"]["value"] > 0 and j["fast_mode"]["bit_exact"] is False and float(j["fast_mode"]["psnr_vs_oracle"]) > 48
+    assert "fast_mode" not in j                                   # the non-bit-exact mode left the product in round 4
     assert j["end_to_end"]["value"] > 0 and "RNLHandler_Process" in j["end_to_end"]["what"]
     assert j["parity"]["mismatches"] == 0 and j["parity"]["psnr"] == "inf" and j["parity"]["pixels"] == 3840 * 2160
     if "stream" in j:

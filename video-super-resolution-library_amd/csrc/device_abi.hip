@@ -543,6 +543,10 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         done(0, H);
         return;
     }
+#ifdef RAISR_HIP_DEV                                                  /* ceiling of a fused blend epilogue: the frame rate with k_blend gone (output wrong) */
+    static const bool skip_blend = getenv("RAISR_HIP_SKIP_BLEND") != nullptr;
+    if (skip_blend) { done(0, H); return; }
+#endif
     dim3 gb((W + 63) / 64, (H + 15) / 16, nz);
     timer_begin(c, "k_blend", s, slot);
     hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);

@@ -162,6 +162,7 @@ template <typename T> struct GradOf { using type = f2; };
 
 
 
+
 // AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
 // LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
 //
