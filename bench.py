@@ -350,6 +350,20 @@ def isolated_kernel_ms(lanes, d_in, d_out, wl, torch, iters=24):
     return iso
 
 
+def symmetric_model(wl):
+    """Does the library run its symmetric filter stage for this workload's FIRST pass?  (at most 16 non-palindromic rows in the bank:
+    csrc/device_abi.hip scan_bank_symmetry; RAISR_HIP_SYM=0 switches it off)"""
+    if wl.asm == 5 or os.environ.get("RAISR_HIP_SYM", "1") == "0":
+        return False
+    import glob
+    f = glob.glob(os.path.join(wl.folder, f"filterbin_*_{wl.bits}"))
+    if not f:
+        return False
+    raw = open(f[0], "rb").read()
+    rows = np.frombuffer(raw[16:], np.uint32).reshape(-1, 121)
+    return int((rows != rows[:, ::-1]).any(axis=1).sum()) <= int(os.environ.get("RAISR_HIP_SYM_MAX_ROWS", "16"))
+
+
 def filtered_zone_px(w, h):
     c_final = 6 + 8 * ((w - 12) // 8)
     return max(0, c_final - 6) * max(0, h - 12)
@@ -376,8 +390,8 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
                 "algorithmic_bytes_per_launch": wl.algo_bytes * batch // launches_per_frame,
                 "frames_per_launch": batch,
                 "lanes_overlapped": lanes_n,
-                "note": "path is vector-L1 / fp32-VALU / LDS bound (~1.3 kFLOP and 512 B of L1-delivered coefficients per output pixel vs 1.25 "
-                        "compulsory bytes); the HBM fraction is reported as required, roofline.l1 and roofline.valu are the binding figures (DESIGN.md s5)"}
+                "note": "the path is neither HBM- nor MFMA-bound (~1.3 kFLOP per output pixel vs 1.25 compulsory bytes): the HBM fraction is reported "
+                        "as required; roofline.valu (algorithmic FLOPs / isolated time vs the fp32 vector peak) and roofline.binding say what limits it (DESIGN.md s5)"}
     if dom in iso:
         roofline["frac_isolated"] = round(wl.algo_bytes / launches_per_frame / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
     # the binding roofline: algorithmic FLOPs of the hash+filter stages over their isolated durations
@@ -398,17 +412,18 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
         if not fp16:                                 # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
             roofline["valu"].update({"sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)})
         roofline["binding"] = "f16-valu" if fp16 else "fp32-valu"
-        # What the fp32 kernel is measured to be bound by (profiles/r03_l1_width_probe.md, r03_C2_texture_path_counters.md):
-        # the filter stage fetches 128 fp32 coefficients per pixel through the vector L1, which delivers ~55 B/clk/CU to the lanes for
-        # this access pattern whatever the load width.  The floor of ANY kernel that sources its coefficients there:
-        bytes_px = 256 if fp16 else 512
+        # Coefficient delivery through the vector L1 (profiles/r03_l1_width_probe.md: ~55 B/clk/CU whatever the load width).  Round 3 took
+        # this floor for the binding one; round 4 halved the bytes (symmetric filter stage) and the kernel moved 2 %: it is reported as a
+        # floor, not as the bound.  What binds the kernel is issue / latency at 16 waves per CU (docs/EXPERIMENTS.md I.1).
+        bytes_px = 256 if (fp16 or symmetric_model(wl)) else 512
         floor_ms = zone * bytes_px / (L1_PROBE_B_PER_CLK_CU * N_CUS * CLOCK_HZ) * 1e3
         roofline["l1"] = {"coefficient_bytes_per_pixel": bytes_px, "probe_rate_B_per_clk_per_cu": L1_PROBE_B_PER_CLK_CU,
                           "floor_ms": round(floor_ms, 4), "isolated_ms": round(iso[dom], 4) if dom in iso else None,
                           "frac": round(floor_ms / iso[dom], 4) if dom in iso else None,
-                          "what": "vector-L1 delivery floor of the filter stage / isolated launch of the dominant kernel"}
+                          "what": "vector-L1 delivery floor of the filter stage's coefficients / isolated launch of the dominant kernel (a floor, not the bound)"}
         if not fp16:
-            roofline["binding"] = "vector-l1 (filter stage), fp32-valu second"
+            roofline["binding"] = ("issue / latency at 16 waves per CU: a wave issues one instruction per ~13 cycles, waits 38 % of its life on barriers and "
+                                   "LDS / L1 latency and 23 % for an issue slot (rocprofv3 SQ counters, docs/EXPERIMENTS.md I.1); fp32-valu utilisation is the figure to watch")
     return roofline
 
 

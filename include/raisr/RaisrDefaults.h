@@ -58,7 +58,7 @@ typedef struct VideoDataType {
     unsigned int   width;      /* samples per row                                                */
     unsigned int   height;     /* rows                                                           */
     unsigned int   step;
-    unsigned int   bitShift;   /* low bits: unused by this backend (as on the reference's CPU path); top bit: RAISR_HIP_INTERLEAVED2 */
+    unsigned int   bitShift;   /* low 8 bits: samples are MSB-aligned by this many bits -- honoured for device frames (asm = HIPExternal), as by the reference's OpenCL path; ignored for host planes, as by its CPU path; top bit: RAISR_HIP_INTERLEAVED2 */
 } VideoDataType;
 
 /* Extension for device frames (asm = HIPExternal) whose chroma is ONE plane of interleaved (U, V) pairs (NV12 / P010, what

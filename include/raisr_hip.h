@@ -99,6 +99,12 @@ int raisr_hip_configure(raisr_hip_ctx *ctx, const raisr_hip_config *cfg);
  * plane keeps its previous contents there. */
 int raisr_hip_set_blending(raisr_hip_ctx *ctx, int blending);
 
+/* MSB-aligned samples of DEVICE frames (P010: 10-bit values stored as value << 6): the device-plane entry points below read
+ * sample = stored >> shift and write stored = sample << shift for Y and chroma, as the reference's OpenCL pre/post-process kernels
+ * do with VideoDataType::bitShift (Raisr_OpenCL_kernel.h:241-276).  0 (default) = LSB-aligned.  Host-plane entries ignore it,
+ * as the reference's CPU path ignores bitShift. */
+int raisr_hip_set_sample_shift(raisr_hip_ctx *ctx, int shift);
+
 /* Hot path ------------------------------------------------------------------------------------
  * Device-resident planes.  Pitches are in BYTES.  `stream` is a hipStream_t (NULL = the
  * context's own stream).  Asynchronous: returns after enqueueing. */

@@ -254,10 +254,13 @@ def test_16bit_depth_against_the_oracle(tmp_path, passes, mode):
     assert np.array_equal(oy, oracle_y(frames["random"], ("x", str(dst), (2, 1), 16, passes, mode, 2, True)))
 
 
-@pytest.mark.parametrize("bits,passes,use_stream", [(8, 1, False), (10, 2, False), (8, 1, True)])
-def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream):
+@pytest.mark.parametrize("bits,passes,use_stream,shift", [(8, 1, False, 0), (10, 2, False, 0), (8, 1, True, 0), (10, 1, False, 6), (10, 2, True, 6)])
+def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream, shift):
     """asm = HIPExternal (RaisrDefaults.h): SetRes / Process take DEVICE pointers (pitched planes) -- the zero-copy
-    counterpart of vf_raisr_opencl.c.  Output compared with the oracle (Y) and the oracle's cheap upscale (chroma)."""
+    counterpart of vf_raisr_opencl.c.  Output compared with the oracle (Y) and the oracle's cheap upscale (chroma).
+    shift = 6: P010-style surfaces, every sample stored as value << 6 and VideoDataType::bitShift = 6 on all six planes (what
+    vf_raisr_opencl.c:111,117 passes): the library shifts down on the way in and up on the way out, as the reference's OpenCL
+    pre/post-process kernels do."""
     import ctypes
     import oracle_py as O
     import raisr_hip as R
@@ -272,14 +275,14 @@ def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream):
     u = synth.random_y(w // 2, h // 2, bits, seed=22).astype(ndt)
     v = synth.random_y(w // 2, h // 2, bits, seed=23).astype(ndt)
 
-    def dev_plane(a, pad):                                  # pitched device plane holding `a`
+    def dev_plane(a, pad):                                  # pitched device plane holding `a` (MSB-aligned by `shift` bits)
         host = np.zeros((a.shape[0], a.shape[1] + pad), ndt)
-        host[:, :a.shape[1]] = a
+        host[:, :a.shape[1]] = a.astype(ndt) << shift
         return torch.from_numpy(host.view(np.int16) if bits != 8 else host).cuda().view(tdt)
 
     def vdt(t, width, height):
         d = R.VideoDataType()
-        d.pData = t.data_ptr(); d.width = width; d.height = height; d.step = t.stride(0) * bps; d.bitShift = 0
+        d.pData = t.data_ptr(); d.width = width; d.height = height; d.step = t.stride(0) * bps; d.bitShift = shift
         return d
     dy, du, dv = dev_plane(y, 16), dev_plane(u, 8), dev_plane(v, 8)
     oy = torch.zeros((2 * h, 2 * w + 32), dtype=tdt, device="cuda")
@@ -302,9 +305,9 @@ def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream):
         R.RNLHandler_SetOpenCLContext(0, 0, None)
     got_y = oy[:, :2 * w].cpu().numpy().view(ndt)
     ref = oracle_y(y, ("x", fold, (2, 1), bits, passes, 1, 2, False))
-    assert np.array_equal(got_y, ref)
-    assert np.array_equal(ou[:, :w].cpu().numpy().view(ndt), O.resize(u, w, h).astype(ndt))
-    assert np.array_equal(ov[:, :w].cpu().numpy().view(ndt), O.resize(v, w, h).astype(ndt))
+    assert np.array_equal(got_y, ref.astype(ndt) << shift)
+    assert np.array_equal(ou[:, :w].cpu().numpy().view(ndt), O.resize(u, w, h).astype(ndt) << shift)
+    assert np.array_equal(ov[:, :w].cpu().numpy().view(ndt), O.resize(v, w, h).astype(ndt) << shift)
 
 
 @pytest.mark.parametrize("bits,asm,passes,mode,depth", [(8, 2, 1, 1, 4), (10, 2, 2, 1, 2), (8, 5, 2, 2, 3), (8, 6, 1, 1, 1)])

@@ -223,6 +223,7 @@ struct raisr_hip_ctx {
     hipEvent_t ev_kern = nullptr;
     bool ev_kern_valid = false;
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
+    bool fused_blend = false;                  // census blend of a tile's interior inside k_hashfilter_ac, k_blend_edges for the rest (RAISR_HIP_FUSED_BLEND=0: k_blend for everything)
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
     int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
@@ -257,6 +258,8 @@ struct raisr_hip_ctx {
     int passW[2] = {0, 0}, passH[2] = {0, 0};
     // frame batches (raisr_hip_process_y_device_batch): the scratch planes exist batch_cap times, back to back; zb_* describe the
     // batch of the call in progress (1 / 0 / 0 outside one)
+    const void* final_out = nullptr;              // the caller's output plane of the frame in progress: the pass that writes it applies sample_shift
+    int sample_shift = 0;                         // device-frame entries: samples are MSB-aligned by this many bits (raisr_hip_set_sample_shift)
     int batch_cap = 1;
     int zb_n = 1;
     size_t zb_in_stride = 0, zb_out_stride = 0;      // elements between consecutive caller planes
@@ -416,6 +419,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
     batch_strides(c, pass, zs_out, P);
+    P.out_shift = out == c->final_out ? c->sample_shift : 0;
     const unsigned nz = (unsigned)c->zb_n;
     int slot;
     if (P.c_final > kMargin && H > 2 * kMargin) {
@@ -512,6 +516,23 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
 #ifdef RAISR_HIP_DEV
             if (launch_dev_variant<TOut>(c, s, pass, lrp, P, gf, H, sym)) {} else
 #endif
+            if (c->fused_blend && !P.randomness && !P.write_hash) {
+                // fused blend: the tile's interior pixels leave the kernel blended; the HR plane only receives what neighbours need
+                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (TOut*)out, out_pitch_elems);
+                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, false, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (TOut*)out, out_pitch_elems);
+                timer_end(c, s, slot);
+                EdgeJobs J{};
+                J.n_row_jobs = (int)gf.y + 1; J.n_col_jobs = (int)gf.x + 1;
+                J.row_last = 5 + 16 * (int)gf.y < H - kMargin ? 5 + 16 * (int)gf.y : H - kMargin;
+                J.col_last = 5 + 64 * (int)gf.x < P.c_final ? 5 + 64 * (int)gf.x : P.c_final;
+                const unsigned gx = (unsigned)((W + 63) / 64), gy = (unsigned)((H + 255) / 256);
+                timer_begin(c, "k_blend_edges", s, slot);
+                hipLaunchKernelGGL((k_blend_edges<TOut>), dim3(gx > gy ? gx : gy, (unsigned)(J.n_row_jobs + J.n_col_jobs), nz), dim3(256), 0, s,
+                                   (const TOut*)lrp, (const float*)c->d_hr[pass], P, J, (TOut*)out, out_pitch_elems);
+                timer_end(c, s, slot);
+                done(0, H);
+                return;
+            } else
                 if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
@@ -583,6 +604,7 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
     const int W = c->passW[pass], H = c->passH[pass];
     PassParams P = make_pass(c, pass, W, H);
     batch_strides(c, pass, zs_out, P);
+    P.out_shift = out == c->final_out ? c->sample_shift : 0;
     const unsigned nz = (unsigned)c->zb_n;
     const Pass16 Q = make_pass16(c, pass, W);
     int slot;
@@ -717,6 +739,7 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_FUSED_BLEND")) c->fused_blend = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
@@ -1143,6 +1166,17 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     return RAISR_HIP_OK;
 }
 
+// MSB-aligned samples of device frames (P010 surfaces: 10-bit values stored as value << 6; VideoDataType::bitShift of the plugin API):
+// every device-plane entry point reads sample = stored >> shift and writes stored = sample << shift, as the reference's OpenCL
+// pre/post-process kernels do (Raisr_OpenCL_kernel.h:241-276).  Host-plane entry points are not affected.
+int raisr_hip_set_sample_shift(raisr_hip_ctx* c, int shift)
+{
+    if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
+    if (shift < 0 || shift > 8 || (shift && c->configured && c->cfg.bits + shift > 16)) return fail(RAISR_HIP_EINVAL, "sample shift out of range for the sample size");
+    c->sample_shift = shift;
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_set_blending(raisr_hip_ctx* c, int blending)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
@@ -1172,14 +1206,16 @@ static int process_y_device_impl(raisr_hip_ctx* c, const void* d_in, size_t in_p
     // u8 for 8-bit, u16 above.  pass-1 LR = cheap upscale of the input (a copy when pass 1 runs at input size).
     const bool fp16 = g.hash_variant == RAISR_HIP_HASH_FP16;
     const bool same = g.passes == 2 && c->passW[0] == c->passW[1] && c->passH[0] == c->passH[1];
+    c->final_out = d_out;
     auto job = [&](auto tag) {
         using T = decltype(tag);
         ResizeParams R0 = make_resize(g.in_width, g.in_height, ipe, c->passW[0], c->passH[0], c->passW[0], g.tie_rule);
         const unsigned nz = (unsigned)c->zb_n;                  // frame batch: one launch per kernel, blockIdx.z = frame
         const size_t plane0 = (size_t)c->passW[0] * c->passH[0], plane1 = (size_t)c->passW[1] * c->passH[1];
         if (nz > 1) { R0.zs_src = c->zb_in_stride; R0.zs_dst = plane0; }
+        R0.in_shift = c->sample_shift;                         // MSB-aligned input samples are shifted down on their way into the LR plane
         // pass 1 at input size (two-pass mode 2, Raisr.cpp:960-975) on a tightly pitched plane: the kernels read it where it lies
-        c->lr0_alias = (g.in_width == c->passW[0] && g.in_height == c->passH[0] && ipe == c->passW[0]) ? d_in : nullptr;
+        c->lr0_alias = (g.in_width == c->passW[0] && g.in_height == c->passH[0] && ipe == c->passW[0] && !c->sample_shift) ? d_in : nullptr;
         if (!c->lr0_alias) launch_resize<T, T>(c, s, d_in, c->d_lr[0], R0, "k_resize", nz);
         if (g.passes == 1) {
             if (fp16) { run_pass16<T>(c, s, 0, d_out, ope, c->zb_out_stride); done(0, g.out_height); } else run_pass<T>(c, s, 0, d_out, ope, nchunks, done, c->zb_out_stride);
@@ -1272,6 +1308,7 @@ int raisr_hip_resize_plane_device_ex(raisr_hip_ctx* c, const void* d_src, int sw
     const int bps = bits == 8 ? 1 : 2;
     ResizeParams R = make_resize(sw, sh, (int)(spitch / bps), dw, dh, (int)(dpitch / bps), c->configured ? c->cfg.tie_rule : 0);
     R.sstep = sstep; R.dstep = dstep;
+    R.in_shift = R.out_shift = c->sample_shift;
     if (bps == 1) launch_resize<uint8_t, uint8_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
     else launch_resize<uint16_t, uint16_t>(c, s, d_src, d_dst, R, "k_resize_chroma");
     HIP_TRY(hipGetLastError());

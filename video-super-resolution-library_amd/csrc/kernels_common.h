@@ -41,6 +41,7 @@ struct PassParams {
     // frame batches (raisr_hip_process_y_device_batch): blockIdx.z = frame; plane f of a batch starts f * zs_* ELEMENTS after plane 0
     // (all 0 for a single frame).  Only the production kernels (k_hashfilter_ac, k_blend, k_hashfilter16, k_blend16) read these.
     size_t zs_lr, zs_hr, zs_hash, zs_out;
+    int out_shift;               // blend kernels: stored sample = value << out_shift (MSB-aligned device frames, see ResizeParams); 0 otherwise
     int tile_y0;                 // first tile row of this launch (k_hashfilter_ac / k_blend launched on a range of tile rows: the host
                                  // path pipelines the download of finished rows with the kernels of the next rows)
 };

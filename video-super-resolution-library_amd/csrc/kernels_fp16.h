@@ -687,6 +687,6 @@ __global__ __launch_bounds__(256) void k_blend16(const TOut* __restrict__ lr, co
                 iv = (int)cl;
             }
         }
-        out[(size_t)y * out_pitch + x] = (TOut)iv;
+        out[(size_t)y * out_pitch + x] = (TOut)(iv << P.out_shift);
     }
 }

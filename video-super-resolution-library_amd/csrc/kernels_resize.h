@@ -17,6 +17,8 @@ struct ResizeParams {
     int narrow;                  // 1: the 32-bit path of k_resize is exact for this geometry (make_resize)
     float rdenx, rdeny, rden2;   // 1 / (2 Dx), 1 / (2 Dy), 1 / (2 * 2 Dx * 2 Dy)
     size_t zs_src, zs_dst;       // frame batches: blockIdx.z = frame, planes zs_* elements apart (0 for a single plane)
+    int in_shift, out_shift;     // MSB-aligned samples of device frames (P010: value << 6, VideoDataType::bitShift): sample = stored >> in_shift,
+                                 // stored = sample << out_shift (the reference's OpenCL pre/post-process kernels, Raisr_OpenCL_kernel.h:241-276)
 };
 
 __device__ __forceinline__ void axis_tap(int d, int S, int D, int size, int& i0, int& i1, int& f)
@@ -70,14 +72,15 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
         const TIn* r0 = src + (size_t)y0 * R.spitch;
         const TIn* r1 = src + (size_t)y1 * R.spitch;
         x0 *= R.sstep; x1 *= R.sstep;
-        const unsigned top = (denx - (unsigned)fx) * (unsigned)r0[x0] + (unsigned)fx * (unsigned)r0[x1];
-        const unsigned bot = (denx - (unsigned)fx) * (unsigned)r1[x0] + (unsigned)fx * (unsigned)r1[x1];
+        const int sh = R.in_shift;
+        const unsigned top = (denx - (unsigned)fx) * ((unsigned)r0[x0] >> sh) + (unsigned)fx * ((unsigned)r0[x1] >> sh);
+        const unsigned bot = (denx - (unsigned)fx) * ((unsigned)r1[x0] >> sh) + (unsigned)fx * ((unsigned)r1[x1] >> sh);
         const unsigned num = (deny - (unsigned)fy) * top + (unsigned)fy * bot;
         const unsigned den = denx * deny;
         const unsigned t = 2u * num + den;
         unsigned q = div_small(t, 2u * den, R.rden2);
         if (R.tie_even && (t - q * 2u * den == 0u) && (q & 1u)) q--;
-        dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)q;
+        dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)(q << R.out_shift);
         return;
     }
     int x0, x1, fx, y0, y1, fy;
@@ -87,13 +90,14 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
     const TIn* r0 = src + (size_t)y0 * R.spitch;
     const TIn* r1 = src + (size_t)y1 * R.spitch;
     x0 *= R.sstep; x1 *= R.sstep;
-    const long long top = (denx - fx) * (long long)r0[x0] + (long long)fx * r0[x1];
-    const long long bot = (denx - fx) * (long long)r1[x0] + (long long)fx * r1[x1];
+    const int sh = R.in_shift;
+    const long long top = (denx - fx) * (long long)(r0[x0] >> sh) + (long long)fx * (r0[x1] >> sh);
+    const long long bot = (denx - fx) * (long long)(r1[x0] >> sh) + (long long)fx * (r1[x1] >> sh);
     const long long num = (deny - fy) * top + fy * bot;
     const long long den = denx * deny;
     long long q = (2 * num + den) / (2 * den);
     if (R.tie_even && ((2 * num + den) % (2 * den) == 0) && (q & 1)) q--;
-    dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)q;
+    dst[(size_t)y * R.dpitch + (size_t)x * R.dstep] = (TOut)(q << R.out_shift);
 }
 
 // 2x special case of the same arithmetic: weights {1,3}/4 per axis, out = (sum + 8) >> 4
@@ -117,15 +121,16 @@ __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, T
     const TIn* rb = src + (size_t)yb * R.spitch;
     const int c = 2 * t;                                      // source columns c-1 .. c+2
     const int cm = max(c - 1, 0), c1 = min(c + 1, R.sw - 1), c2 = min(c + 2, R.sw - 1), cc = min(c, R.sw - 1);
-    const int a0 = ra[cm], a1 = ra[cc], a2 = ra[c1], a3 = ra[c2];
-    const int b0 = rb[cm], b1 = rb[cc], b2 = rb[c1], b3 = rb[c2];
+    const int sh = R.in_shift;
+    const int a0 = ra[cm] >> sh, a1 = ra[cc] >> sh, a2 = ra[c1] >> sh, a3 = ra[c2] >> sh;
+    const int b0 = rb[cm] >> sh, b1 = rb[cc] >> sh, b2 = rb[c1] >> sh, b3 = rb[c2] >> sh;
     const int v0 = wa * a0 + wb * b0, v1 = wa * a1 + wb * b1, v2 = wa * a2 + wb * b2, v3 = wa * a3 + wb * b3;
     int o[4] = {v0 + 3 * v1, 3 * v1 + v2, v1 + 3 * v2, 3 * v2 + v3};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int q = (o[i] + 8) >> 4;
         if (R.tie_even && ((o[i] & 15) == 8) && (q & 1)) q--;
-        o[i] = q;
+        o[i] = q << R.out_shift;
     }
     TOut* d = dst + (size_t)y * R.dpitch + x0;
     if (x0 + 3 < R.dw) {
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c = min(max(2 * m - 1 + i, 0), R.sw - 1);
-        v[i] = gy * (unsigned)ra[c] + fy * (unsigned)rb[c];
+        v[i] = gy * ((unsigned)ra[c] >> R.in_shift) + fy * ((unsigned)rb[c] >> R.in_shift);
     }
     TOut* d = dst + (size_t)y * R.dpitch + x0;
 #pragma unroll
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, 
         const unsigned t = 2u * num + 36u;
         unsigned q = t / 72u;
         if (R.tie_even && t - 72u * q == 0u && (q & 1u)) q--;
-        d[e] = (TOut)q;
+        d[e] = (TOut)(q << R.out_shift);
     }
 }
 
@@ -185,6 +190,6 @@ __global__ __launch_bounds__(256) void k_copy(const TIn* __restrict__ src, TOut*
     src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < R.dw && y < R.dh) dst[(size_t)y * R.dpitch + x] = (TOut)src[(size_t)y * R.spitch + x];
+    if (x < R.dw && y < R.dh) dst[(size_t)y * R.dpitch + x] = (TOut)((src[(size_t)y * R.spitch + x] >> R.in_shift) << R.out_shift);
 }
 

@@ -567,6 +567,10 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         // NV12 / P010 surfaces: both chroma descriptors flag one interleaved plane (RaisrDefaults.h) -- all four or none
         const unsigned il = (inCr->bitShift & inCb->bitShift & outCr->bitShift & outCb->bitShift) & RAISR_HIP_INTERLEAVED2;
         if (((inCr->bitShift | inCb->bitShift | outCr->bitShift | outCb->bitShift) & RAISR_HIP_INTERLEAVED2) && !il) return RNLErrorBadParameter;
+        // bitShift (low bits): samples of the surface are MSB-aligned by that many bits (P010: 6), the same on every plane
+        const unsigned sh = inY->bitShift & 0xFFu;
+        for (const VideoDataType *p : {inCr, inCb, outY, outCr, outCb}) if ((p->bitShift & 0xFFu) != sh) return RNLErrorBadParameter;
+        if (raisr_hip_set_sample_shift(G.ctx, (int)sh) != RAISR_HIP_OK) return RNLErrorBadParameter;
         int rc = raisr_hip_process_frame_device_ex(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
                                                    inCr->pData, inCb->pData, inCr->step, outCr->pData, outCb->pData, outCr->step,
                                                    (int)inCr->width, (int)inCr->height, (int)outCr->width, (int)outCr->height, il ? 2 : 1, G.externalStream);
