@@ -223,7 +223,6 @@ struct raisr_hip_ctx {
     hipEvent_t ev_kern = nullptr;
     bool ev_kern_valid = false;
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
-    bool fused_blend = false;                  // census blend of a tile's interior inside k_hashfilter_ac, k_blend_edges for the rest (RAISR_HIP_FUSED_BLEND=0: k_blend for everything)
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
     int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
@@ -516,23 +515,6 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
 #ifdef RAISR_HIP_DEV
             if (launch_dev_variant<TOut>(c, s, pass, lrp, P, gf, H, sym)) {} else
 #endif
-            if (c->fused_blend && !P.randomness && !P.write_hash) {
-                // fused blend: the tile's interior pixels leave the kernel blended; the HR plane only receives what neighbours need
-                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (TOut*)out, out_pitch_elems);
-                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, false, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], (TOut*)out, out_pitch_elems);
-                timer_end(c, s, slot);
-                EdgeJobs J{};
-                J.n_row_jobs = (int)gf.y + 1; J.n_col_jobs = (int)gf.x + 1;
-                J.row_last = 5 + 16 * (int)gf.y < H - kMargin ? 5 + 16 * (int)gf.y : H - kMargin;
-                J.col_last = 5 + 64 * (int)gf.x < P.c_final ? 5 + 64 * (int)gf.x : P.c_final;
-                const unsigned gx = (unsigned)((W + 63) / 64), gy = (unsigned)((H + 255) / 256);
-                timer_begin(c, "k_blend_edges", s, slot);
-                hipLaunchKernelGGL((k_blend_edges<TOut>), dim3(gx > gy ? gx : gy, (unsigned)(J.n_row_jobs + J.n_col_jobs), nz), dim3(256), 0, s,
-                                   (const TOut*)lrp, (const float*)c->d_hr[pass], P, J, (TOut*)out, out_pitch_elems);
-                timer_end(c, s, slot);
-                done(0, H);
-                return;
-            } else
                 if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
                 else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
             timer_end(c, s, slot);
@@ -739,7 +721,6 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
-    if (const char* e = getenv("RAISR_HIP_FUSED_BLEND")) c->fused_blend = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);

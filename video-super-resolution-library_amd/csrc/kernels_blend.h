@@ -151,76 +151,3 @@ __global__ __launch_bounds__(256) void k_blend_rand(const TOut* __restrict__ lr,
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// k_blend_edges: the pixels the fused blend of k_hashfilter_ac<.., FB> leaves out -- everything outside the INTERIOR of a filter
-// tile (tile rows 1..14, columns 1..62 of the 64 x 16 tiles that start at (6, 6), inside the filtered zone): the frame's border band,
-// the two pixel rows on either side of every tile-row boundary and the two pixel columns on either side of every tile-column
-// boundary, ~15 % of a frame.  Same arithmetic as k_blend.  HR of a neighbour: the HR plane where the fused kernel wrote it (the two
-// outermost rows / columns of every tile and of the zone -- exactly what these pixels' 3 x 3 windows reach), LR outside the zone
-// (Raisr.cpp:1035).  blockIdx.y < n_row_jobs: a job of <= 8 full-width rows (lane = column); otherwise a job of <= 16 columns over the
-// rows no row job covers (thread = row).
-// ------------------------------------------------------------------------------------------------
-struct EdgeJobs {
-    int n_row_jobs, n_col_jobs;      // tile rows + 1, tile columns + 1
-    int row_last, col_last;          // first row / column of the last job: min(5 + 16 Ty, H - 6), min(5 + 64 Tx, c_final)
-};
-
-__device__ __forceinline__ bool edge_row(int r, const EdgeJobs& J) { return r < 7 || r >= J.row_last || ((r - 5) & 15) < 2; }
-
-template <typename TOut>
-__device__ __forceinline__ void blend_edge_px(const TOut* __restrict__ lr, const float* __restrict__ hr, const PassParams& P,
-                                              TOut* __restrict__ out, int out_pitch, int y, int x)
-{
-    const float Lc = (float)lr[(size_t)y * P.lr_pitch + x];
-    int iv;
-    if (x == 0 || y == 0 || x == P.W - 1 || y == P.H - 1) {
-        iv = (int)Lc;                                           // unclamped LR copy
-    } else {
-        auto zone = [&](int yy, int xx) { return yy >= kMargin && yy < P.H - kMargin && xx >= kMargin && xx < P.c_final; };
-        const float Hc = zone(y, x) ? hr[(size_t)y * P.hr_pitch + x] : Lc;
-        int hd = 0;
-#pragma unroll
-        for (int i = -1; i <= 1; i++)
-#pragma unroll
-            for (int j = -1; j <= 1; j++) {
-                if (i == 0 && j == 0) continue;
-                const float l = (float)lr[(size_t)(y + i) * P.lr_pitch + x + j];
-                const float h = zone(y + i, x + j) ? hr[(size_t)(y + i) * P.hr_pitch + x + j] : l;
-                hd += ((l < Lc) != (h < Hc));
-            }
-        const float weight = (float)hd * 0.125f;
-        const float w2 = 1.0f - weight;
-        float val = (weight * Lc) + (w2 * Hc);
-        val = val + 0.5f;
-        const float fl = __builtin_floorf(val);
-        iv = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
-        iv = max(min(iv, P.ihi), P.ilo);
-    }
-    out[(size_t)y * out_pitch + x] = (TOut)(iv << P.out_shift);
-}
-
-template <typename TOut>
-__global__ __launch_bounds__(256) void k_blend_edges(const TOut* __restrict__ lr, const float* __restrict__ hr, PassParams P, EdgeJobs J,
-                                                     TOut* __restrict__ out, int out_pitch)
-{
-    lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; out += blockIdx.z * P.zs_out;          // frame batches
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if ((int)blockIdx.y < J.n_row_jobs) {
-        // rows [ra, rb): job 0 = the top band and the first tile row's row 0; job k = rows 5 + 16 k and 6 + 16 k; the last job = the
-        // bottom band (and the last tile row's row 15 when the zone reaches it)
-        const int k = (int)blockIdx.y;
-        const int ra = k == 0 ? 0 : (k == J.n_row_jobs - 1 ? J.row_last : 5 + 16 * k);
-        const int rb = k == 0 ? 7 : (k == J.n_row_jobs - 1 ? P.H : 7 + 16 * k);
-        const int x = (int)blockIdx.x * 64 + lane;
-        if (x >= P.W) return;
-        for (int y = ra + w; y < min(rb, P.H); y += 4) blend_edge_px(lr, hr, P, out, out_pitch, y, x);
-    } else {
-        // columns [ca, cb) of the rows no row job covers: one thread per row
-        const int m = (int)blockIdx.y - J.n_row_jobs;
-        const int ca = m == 0 ? 0 : (m == J.n_col_jobs - 1 ? J.col_last : 5 + 64 * m);
-        const int cb = m == 0 ? 7 : (m == J.n_col_jobs - 1 ? P.W : 7 + 64 * m);
-        const int y = (int)blockIdx.x * 256 + (int)threadIdx.x;
-        if (y >= P.H || edge_row(y, J)) return;
-        for (int x = ca; x < min(cb, P.W); x++) blend_edge_px(lr, hr, P, out, out_pitch, y, x);
-    }
-}

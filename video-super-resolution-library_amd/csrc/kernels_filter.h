@@ -58,11 +58,9 @@ __device__ __forceinline__ float partner_xchg(float v)      // lane p of every r
 
 // filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
-// FB (fused blend, k_hashfilter_ac only): the row's HR values go to the LDS tile sHR [16][64] for blend_interior, and to the HR
-// plane only where another tile or k_blend_edges needs them (the two outermost rows / columns of the tile and of the filtered zone).
-template <int LW, int RPW = 4, bool SYM = false, bool FB = false>
+template <int LW, int RPW = 4, bool SYM = false>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
-                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x, float* sHR = nullptr)
+                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x)
 {
     constexpr int TW = 64;
     const int lane = tid & 63, w = tid >> 6;
@@ -215,60 +213,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #undef RAISR_LDS_F
 #undef RAISR_BANK_F
         const int c = c0 + 4 * sl + g;
-        if (FB) {
-            const int lc = 4 * sl + g;
-            sHR[prow * TW + lc] = keep;                          // (= LR for a pixel outside the filtered zone: its bucket is 0xFF)
-            const bool ring = prow < 2 || prow >= 4 * RPW - 2 || lc < 2 || lc >= TW - 2 || r >= P.H - kMargin - 2 || c >= P.c_final - 2;
-            if (ring && r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
-        } else if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
-    }
-}
-
-// Census blend of a tile's INTERIOR pixels (tile rows 1..14, columns 1..62, inside the filtered zone) straight from LDS: the LR window
-// (sLf: origin (r0-5, c0-5), stride LW) and the HR tile filter_phase<.., FB> left in sHR -- every neighbour of an interior pixel lies in
-// the tile.  Same operations as k_blend (kernels_blend.h: CTCountOfBitsChangedSegment_AVX256_32f, Raisr_AVX256.cpp:68-166); the
-// remaining pixels are k_blend_edges'.  Wave w owns tile rows [4w, 4w+4), lane = column.
-template <typename TOut, int LW>
-__device__ __forceinline__ void blend_interior(const PassParams& P, const float* sLf, const float* sHR, int c0, int r0,
-                                               TOut* __restrict__ out, int out_pitch, unsigned tid = threadIdx.x)
-{
-    constexpr int TW = 64;
-    const int lane = tid & 63, w = tid >> 6;
-    const int x = c0 + lane;
-    const int lm = max(lane - 1, 0), lp = min(lane + 1, TW - 1);       // (lanes 0 and 63 compute nothing they keep)
-    float l[3][3], h[3][3];
-    auto load_row = [&](int i, int prow) {                              // neighbour row `prow` of the tile into window row i
-        const int pr = min(max(prow, 0), 15);
-        l[i][0] = sLf[(prow + 5) * LW + lane + 4]; l[i][1] = sLf[(prow + 5) * LW + lane + 5]; l[i][2] = sLf[(prow + 5) * LW + lane + 6];
-        h[i][0] = sHR[pr * TW + lm]; h[i][1] = sHR[pr * TW + lane]; h[i][2] = sHR[pr * TW + lp];
-    };
-    load_row(1, 4 * (int)w - 1);
-    load_row(2, 4 * (int)w);
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int prow = 4 * w + rr, y = r0 + prow;
-#pragma unroll
-        for (int j = 0; j < 3; j++) { l[0][j] = l[1][j]; l[1][j] = l[2][j]; h[0][j] = h[1][j]; h[1][j] = h[2][j]; }
-        load_row(2, prow + 1);
-        const bool mine = prow >= 1 && prow <= 14 && lane >= 1 && lane <= TW - 2 && y < P.H - kMargin && x < P.c_final;
-        if (!mine) continue;
-        const float Lc = l[1][1], Hc = h[1][1];
-        int hd = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                if (i == 1 && j == 1) continue;
-                hd += ((l[i][j] < Lc) != (h[i][j] < Hc));
-            }
-        const float weight = (float)hd * 0.125f;                   // hd / 8.0f exactly
-        const float w2 = 1.0f - weight;
-        float val = (weight * Lc) + (w2 * Hc);
-        val = val + 0.5f;
-        const float fl = __builtin_floorf(val);
-        int iv = (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
-        iv = max(min(iv, P.ihi), P.ilo);
-        out[(size_t)y * out_pitch + x] = (TOut)(iv << P.out_shift);
+        if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
 }
 
@@ -349,11 +294,10 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
 // one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
-template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false, bool FB = false>
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false>
 __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
                                                    uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
-                                                   float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x,
-                                                   T* __restrict__ out = nullptr, int out_pitch = 0)
+                                                   float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x)
 {
     constexpr int TW = 64, TH = 4 * RPW;
     static_assert(LH == TH + 12 && GH == TH + 10, "window and gradient tile follow the tile height");
@@ -404,22 +348,13 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
-    if (FB) {
-        // fused blend: the gradient tile's space (every wave is past the hash stage's last barrier) takes the tile's HR values
-        static_assert(!FB || (RPW == 4 && sizeof(GT) * GH * GW_ >= sizeof(float) * TH * TW), "HR tile fits the gradient tile's space");
-        float* sHR = reinterpret_cast<float*>(sG);
-        filter_phase<LW, RPW, SYM, true>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, sHR);
-        __syncthreads();
-        blend_interior<T, LW>(P, sL + LW + 1, sHR, c0, r0, out, out_pitch, tid);
-    } else
     if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
 }
 
-template <typename T, int PART = 0, int RPW = 4, bool SYM = false, bool FB = false>
+template <typename T, int PART = 0, int RPW = 4, bool SYM = false>
 __global__ __launch_bounds__(256, RPW == 4 ? 4 : 6) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
-                                                                         uint8_t* __restrict__ hash_out, float* __restrict__ hr,
-                                                                         T* __restrict__ out = nullptr, int out_pitch = 0)
+                                                                         uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
     constexpr int TW = 64, TH = 4 * RPW;
     constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
@@ -437,8 +372,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 4 : 6) void k_hashfilter_ac(const T
     xcd_tile(bx, by);
     by += P.tile_y0;
     lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
-    if (FB) out += blockIdx.z * P.zs_out;
-    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM, FB>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, threadIdx.x, out, out_pitch);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt);
 }
 
 
