@@ -763,8 +763,18 @@ static int create_impl(raisr_hip_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->d_lut, lut.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(c->d_tab14, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    std::vector<uint16_t> t16(3072);
+    std::vector<uint16_t> t16(3072 + 2048);
     for (int i = 0; i < 1024; i++) { t16[i] = X86_RCPPH_T[i]; t16[1024 + i] = X86_RSQRTPH_T0[i]; t16[2048 + i] = X86_RSQRTPH_T1[i]; }
+    // composite VRCPPH(VRSQRTPH(x)) for positive finite x (kernels_fp16.h, sqrt_ph): VRSQRTPH gives mantissa + exponent te of row t
+    // (less the halved input exponent), VRCPPH of that the row t2 of its mantissa with exponent te2 + 15 - (te - half); folded:
+    // C[p][m] = ((te2 + 15 - te) << 10) | mantissa(t2), result = C + (half << 10).  te2 + 15 - te is 13..16 for every row.
+    for (int p = 0; p < 2; p++)
+        for (int m = 0; m < 1024; m++) {
+            const unsigned t = t16[1024 + 1024 * p + m], t2 = t16[t & 1023u];
+            const int base = (int)((t2 >> 10) & 31u) + 15 - (int)((t >> 10) & 31u);
+            if (base < 8 || base > 23) return fail(RAISR_HIP_ERUNTIME, "composite square-root table: exponent out of the expected range");
+            t16[3072 + 1024 * p + m] = (uint16_t)(((unsigned)base << 10) | (t2 & 1023u));
+        }
     HIP_TRY(hipMalloc((void**)&c->d_tab16, t16.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(c->d_tab16, t16.data(), t16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());           // (null-stream copies are not ordered with the non-blocking streams the kernels use)

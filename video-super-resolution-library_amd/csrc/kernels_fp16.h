@@ -22,7 +22,7 @@ struct GaussW16 {
 struct Pass16 {
     const uint32_t* bank16;      // [hash][type][4 chunks][16 lanes] half2 = (f[32c+l], f[32c+l+16]), taps >= 121 are +0
     int bank16_bytes;            // size of the binary16 bank (buffer-descriptor range)
-    const uint16_t* tab16;       // rcpph T[1024], rsqrtph T0[1024], T1[1024]
+    const uint16_t* tab16;       // rcpph T[1024], rsqrtph T0[1024], T1[1024], then the composite VRCPPH(VRSQRTPH(.)) table C[2][1024] (sqrt_ph)
     uint16_t qangle, qs0, qs1, qc0, qc1;   // binary16 bit patterns
     float nf;                    // NF_8 (fp32), Raisr_globals.h:208
     int c_avx;                   // first column of the blend stage's scalar (fp32) tail
@@ -107,8 +107,10 @@ __device__ __attribute__((noinline)) uint16_t sqrt_ph_generic(uint16_t x, const 
 //            exponent te2 + 15 - (te - half), in 2..23: none of the generic model's range checks can fire;
 //   +-0 -> +-inf -> +-0;   negative (normal or denormal) -> QNaN 0xfe00 -> 0xfe00;
 //   +-inf, NaN -> `rare`: the caller recomputes with the generic model.
-__device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab, bool& rare)
+__device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* ctab, bool& rare)
 {
+    // ctab = the two look-ups folded into one (device_abi.hip, composite_sqrt_table): C[p][m] = ((te2 + 15 - te) << 10) | mantissa of
+    // VRCPPH's row for VRSQRTPH's mantissa, so that the result is C[p][m] + (half << 10) -- one LDS read instead of two dependent ones
     const uint32_t x = h_u(v);
     uint32_t m = x & 1023u;
     int E = (int)((x >> 10) & 31u);
@@ -117,10 +119,7 @@ __device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab, bool& rare)
     m = den ? ((m << lz) & 1023u) : m;
     E = den ? 1 - lz : E;
     const int ue = E - 15, p = ue & 1, half = (ue - p) >> 1;
-    const uint32_t t = tab[1024 + 1024 * p + (int)m];
-    const uint32_t t2 = tab[t & 1023u];
-    const int re = (int)((t2 >> 10) & 31u) + 15 - (int)((t >> 10) & 31u) + half;
-    uint32_t z = ((uint32_t)re << 10) | (t2 & 1023u);
+    uint32_t z = (uint32_t)((int)ctab[1024 * p + (int)m] + half * 1024);
     const bool zero = (x & 0x7fffu) == 0u;
     const bool negative = (x & 0x8000u) != 0u;
     z = negative ? 0xfe00u : z;
@@ -134,6 +133,7 @@ __device__ __forceinline__ hf sqrt_ph(hf v, const uint16_t* tab, bool& rare)
 // thresholds BY VALUE: a reference into the kernel-argument struct would force it into scratch for the out-of-line variant
 struct HashQ16 { uint16_t qangle, qs0, qs1, qc0, qc1, ls0, ls1; float cm0, cm1; int ct0, ct1, fold; };
 
+// tab: FAST -> the composite table (in LDS); else the three instruction tables (global memory: only pixels that saw an infinity or a NaN)
 template <bool FAST>
 __device__ __forceinline__ int hash_px16_impl(hf a, hf b, hf d, const HashQ16 Q, const uint16_t* tab, bool& rare)
 {
@@ -333,7 +333,7 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
             const hf a = h_scale_f32(e ? a2.y : a2.x, Q.nf), b = h_scale_f32(e ? b2.y : b2.x, Q.nf), d = h_scale_f32(e ? d2.y : d2.x, Q.nf);
             bool rare = false;
             unsigned h = (unsigned)hash_px16_impl<true>(a, b, d, HQ, sTab, rare);
-            if (rare) h = (unsigned)hash_px16_generic(a, b, d, HQ, sTab);
+            if (rare) h = (unsigned)hash_px16_generic(a, b, d, HQ, Q.tab16);
             hA[j] = (r < P.H - kMargin && c < P.c_final) ? h : 0xFFu;
         }
     }
@@ -347,13 +347,13 @@ __global__ __launch_bounds__(256, 4) void k_hash16(const T* __restrict__ lr, Pas
     constexpr int LW = 76, LH = TH + 12;
     __shared__ hf sL[LH * LW];
     __shared__ uint2 sG[(TH + 9) * 74];
-    __shared__ uint16_t sTab[3072];
+    __shared__ uint16_t sTab[2048];          // composite square-root table (sqrt_ph)
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bx, by;
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * 64, r0 = kMargin + by * TH;
-    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
+    for (int i = threadIdx.x; i < 2048; i += 256) sTab[i] = Q.tab16[3072 + i];
     stage_tile<LH, LW, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);   // u8 -> binary16 is exact for 8-bit content
     __syncthreads();
     unsigned hA[R];
@@ -539,12 +539,12 @@ __device__ __forceinline__ void build_pair_windows(const hf* sW, uint32_t* sPA, 
 // k_hashfilter16: both binary16 stages of a tile in one launch (see k_hashfilter).  The hash stage's gradient tile and tables and
 // the filter stage's pair windows share one LDS region (a workgroup barrier on either side of build_pair_windows).
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
+__global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ lr, PassParams P, Pass16 Q, GaussW16 gw,
                                                          uint8_t* __restrict__ hash_out, uint16_t* __restrict__ hr)
 {
     constexpr int R = 4, TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12;
-    constexpr int kGBytes = (TH + 9) * 74 * 8, kTabBytes = 3072 * 2, kPairBytes = 26 * LW * 4;
+    constexpr int kGBytes = (TH + 9) * 74 * 8, kTabBytes = 2048 * 2, kPairBytes = 26 * LW * 4;
     static_assert(2 * kPairBytes <= kGBytes + kTabBytes, "the pair windows fit the hash stage's region");
     __shared__ hf sL[LH * LW];
     __shared__ __attribute__((aligned(16))) unsigned char sRegion[kGBytes + kTabBytes];
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter16(const T* __restrict__ l
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
     lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
-    for (int i = threadIdx.x; i < 3072; i += 256) sTab[i] = Q.tab16[i];
+    for (int i = threadIdx.x; i < 2048; i += 256) sTab[i] = Q.tab16[3072 + i];
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
     __syncthreads();
     unsigned hA[R];
