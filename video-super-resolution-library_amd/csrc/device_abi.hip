@@ -1749,6 +1749,18 @@ int raisr_hip_debug_approx_hash(raisr_hip_ctx* c, int pass_index, int hash_flavo
     return rc;
 }
 
+#ifdef RAISR_HIP_DEV
+// development builds: wave-cycles per phase of k_hashfilter_ac since the last call (kernels_common.h g_phase_cycles); clears them
+int raisr_hip_dev_phase_stats(unsigned long long out[8])
+{
+    if (hipDeviceSynchronize() != hipSuccess) return fail(RAISR_HIP_ERUNTIME, "hipDeviceSynchronize");
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return fail(RAISR_HIP_ERUNTIME, "hipMemcpyFromSymbol");
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess) return fail(RAISR_HIP_ERUNTIME, "hipMemcpyToSymbol");
+    return RAISR_HIP_OK;
+}
+#endif
+
 // Test hook: exhaustive comparison of the binary16 hash's folded thresholds (Pass16) with the divisions they replace, for
 // pass `pass_index`'s model.  out[0] = disagreements (must be 0), out[1] = operand pairs compared (~2^31).
 int raisr_hip_debug_fold16_check(raisr_hip_ctx* c, int pass_index, unsigned long long out[2])

@@ -46,6 +46,26 @@ struct PassParams {
                                  // path pipelines the download of finished rows with the kernels of the next rows)
 };
 
+#ifdef RAISR_HIP_DEV
+// development builds: wave-cycles per phase of the fused kernel (s_memtime at the phase boundaries of every wave, summed over the launch;
+// the instrumentation itself costs ~10 % -- read the shares, not the totals).  raisr_hip_dev_phase_stats() reads and clears them.
+__device__ unsigned long long g_phase_cycles[8];
+__device__ __forceinline__ void phase_mark(unsigned long long& t, int k, unsigned tid)
+{
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    // one workgroup in 61 reports (every wave reporting serialises 32 k waves x 7 atomics on eight addresses: the kernel ran 10x slower)
+    if ((tid & 63u) == 0 && (blockIdx.y * gridDim.x + blockIdx.x) % 61u == 0u) atomicAdd(&g_phase_cycles[k], now - t);
+    t = now;
+}
+#define RAISR_PHASE_DECL unsigned long long phase_t = __builtin_amdgcn_s_memtime()
+#define RAISR_PHASE(k) phase_mark(phase_t, (k), tid)
+#define RAISR_PHASE_RESET phase_t = __builtin_amdgcn_s_memtime()
+#else
+#define RAISR_PHASE_DECL
+#define RAISR_PHASE(k)
+#define RAISR_PHASE_RESET
+#endif
+
 // XCD-aware tile order.  The dispatcher hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md) and
 // each XCD has a private 4 MiB L2, so with the plain (blockIdx.x, blockIdx.y) order the eight tiles around
 // any tile live in eight different L2s and every halo row/column is fetched from HBM again.  Remap the

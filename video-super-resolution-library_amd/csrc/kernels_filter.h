@@ -85,7 +85,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
-#pragma unroll 1
+#pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
     for (int row = 0; row < RPW; row++) {
         const int prow = RPW * w + row;
         const int r = r0 + prow;
@@ -304,9 +304,11 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     const int lane = tid & 63, w = tid >> 6;
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
+    RAISR_PHASE_DECL;
     if (tid < 3) sCnt[tid] = 0;
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL, tid);
     __syncthreads();
+    RAISR_PHASE(0);
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
@@ -327,6 +329,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         }
     }
     __syncthreads();
+    RAISR_PHASE(1);
 #ifdef RAISR_HIP_DEV
     if (PART == 2) {     // profiling aid: filter stage only; P.cert_check doubles as the bucket pattern (0 = every row of the bank, 1 = one row, 2 = sixteen rows)
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
@@ -334,6 +337,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     } else
 #endif
     hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
+    RAISR_PHASE_RESET;                                     // (the hash stage keeps its own marks 2..5)
     if (P.write_hash) {
         const int c = c0 + lane;
 #pragma unroll
@@ -350,6 +354,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     }
     if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
+    RAISR_PHASE(6);
 }
 
 template <typename T, int PART = 0, int RPW = 4, bool SYM = false>

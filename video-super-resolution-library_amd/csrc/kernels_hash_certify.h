@@ -246,7 +246,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     const int lane = tid & 63, w = tid >> 6;
     if (tid == 0) sCnt[0] = 0;
     float ta[RPW], tb[RPW], td[RPW];
+    RAISR_PHASE_DECL;
     tensor_acN<RPW, GT>(S, sG, sV, ta, tb, td, tid);
+    RAISR_PHASE(2);                                        // V pass + barrier + H pass
     // ---- approximate hash + certification of the lane's 4 pixels ----
     const int c = c0 + lane;
     const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
@@ -280,7 +282,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     if (P.cert_stats) {
         if (nUnc) atomicAdd(&sCnt[1], nUnc);
     }
+    RAISR_PHASE(3);                                        // approximate hash + certification
     __syncthreads();
+    RAISR_PHASE(4);                                        // ... wait for the other waves
 
     // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
@@ -337,6 +341,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
     if (n) __syncthreads();                                // (n is the same in every thread)
+    RAISR_PHASE(5);                                        // worklist: table staging, exact tensors, exact hashes, three barriers
 }
 
 // Test hook: the certified hash stage's decision for arbitrary APPROXIMATE tensor triples (a', b', d'): bucket and whether
