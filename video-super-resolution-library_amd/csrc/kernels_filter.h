@@ -42,11 +42,16 @@ __device__ __forceinline__ float tree16(float acc)
 // Every chain still sees its eight fused multiply-adds in the reference's order; the 16 sums end up permuted by
 // l -> (8 - l) & 15, which maps the summation tree of sumitup_ps_512 onto itself (it flips tree levels only), so the
 // tree's result is the same bits.  For l >= 9 the chain's padding step (p = +0, f = +0: acc + (+0)) runs as the FIFTH step
-// instead of the eighth so that both lane classes use the registers (c3 | +0, c2, c1, c0) for steps 4..7; moving
-// "+ (+0)" inside the chain cannot change its value: it only turns -0 into +0, which the reference's final padding step
-// does anyway, and a chain that is -0 at any point consists of -0 products only.  (tests/test_sym_filter_model.py replays
-// this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes are listed in P.asym;
-// their pixels are redone with the full eight loads after the row's main loop.
+// instead of the eighth so that both lane classes use the registers (c3, c2, c1, c0) for steps 4..7, and it runs as
+// fma(+0, c3, acc): the lane reads its "pixel" from a block of zeros instead of masking the coefficient (one select per
+// tile row instead of one per step).  Signed zeros: the product is +0 or -0 by the sign of c3, so the step leaves acc as it
+// is, except that -0 + (+0) = +0.  A chain value of -0 can only come from -0 products on a -0 accumulator (an exact
+// cancellation rounds to +0), so moving the step inside the chain, or skipping it, changes nothing unless the chain's
+// eight products are all -0 -- then this lane ends with -0 or +0 where the reference has +0.  A zero chain adds nothing to
+// a tree whose total is not zero, and a zero total fails the accept test either way (clamp_lo >= 0, checked at configure),
+// so the pixel keeps LR in both cases: every stored value has the reference's bits.  (tests/test_sym_filter_model.py
+// replays this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes are listed in
+// P.asym; their pixels are redone with the full eight loads after the row's main loop.
 __device__ __forceinline__ float partner_xchg(float v)      // lane p of every row of 16 receives lane (8 - p) & 15
 {
     // (every lane of a row has a source lane: `old` is never used, so it is the source itself and no register is zeroed for it)
@@ -60,7 +65,7 @@ __device__ __forceinline__ float partner_xchg(float v)      // lane p of every r
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
 template <int LW, int RPW = 4, bool SYM = false>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
-                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x)
+                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x, const float* zpad = nullptr)
 {
     constexpr int TW = 64;
     const int lane = tid & 63, w = tid >> 6;
@@ -76,7 +81,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
         asm volatile("" : "+v"(off[ch]));                      // one register per tap: left alone, the compiler keeps row and column part apart (16 VGPRs)
     }
-    const unsigned maskA = (SYM && l >= 9) ? 0u : 0xFFFFFFFFu;   // SYM: step 4 multiplies by c3 (l <= 8) or by +0 (the padding step of l >= 9)
+    // SYM: step 4 is tap 64 + l2 times c3 for l <= 8 and the padding step for l >= 9, whose window address points at zpad (64 floats
+    // of +0 owned by this wave): p = +0 times c3 -- see the note on signed zeros above.
 
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
     const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -95,8 +101,15 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         const char* tap[8];
 #pragma unroll
         for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off[ch]);
+        if (SYM) tap[4] = l >= 9 ? reinterpret_cast<const char*>(zpad) : tap[4];
         const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
+#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_NO_WINDOW)
+        // TIMING PROBE, output wrong: every step reads step 0's window values, so the compiler keeps them in registers: eight LDS
+        // reads per row instead of 128
+#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p)))
+#else
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
+#endif
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         // The plain 16-lane chains of one step with all eight loads (tail re-hash and, in the symmetric variant, the pixels of
         // non-palindromic rows).  The symmetric variant has no registers for the plain tap offsets: it recomputes them here, behind
@@ -132,6 +145,12 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // bit).  Lane l ends up with the result of step sl = bitrev4(l): merge level 1 puts step bit 0 on lane bit 3, ..., level 4
         // step bit 3 on lane bit 0.
         float A16[16];
+#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_COEF_REUSE)
+        // TIMING PROBE, output wrong: coefficients are fetched for every RAISR_EXP_COEF_REUSE-th step only and reused for the steps
+        // between -- what any scheme that shares coefficient rows between pixels (key-chunked stage) could gain at most, with
+        // its sort, scattered window reads and scattered stores for free (docs/EXPERIMENTS.md I.4).
+        float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const unsigned hA = sH[prow * TW + 4 * s + g];
@@ -139,18 +158,31 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
             const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
             float acc;
+#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_COEF_REUSE)
+            if (s % RAISR_EXP_COEF_REUSE == 0) {
+#pragma unroll
+                for (int ch = 0; ch < (SYM ? 4 : 8); ch++) qr[ch] = RAISR_BANK_F(voff + 64u * ch);
+            }
+            if (!SYM) {
+                acc = RAISR_LDS_F(tap[0], s) * qr[0];
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), qr[ch], acc);
+            } else {
+                const float q0 = qr[0], q1 = qr[1], q2 = qr[2], q3 = qr[3];
+#else
             if (!SYM) {
                 acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
             } else {
                 const float q0 = RAISR_BANK_F(voff), q1 = RAISR_BANK_F(voff + 64u), q2 = RAISR_BANK_F(voff + 128u), q3 = RAISR_BANK_F(voff + 192u);
+#endif
                 acc = RAISR_LDS_F(tap[0], s) * q0;
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[2], s), q2, acc);
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[3], s), q3, acc);
                 acc = partner_xchg(acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), __uint_as_float(__float_as_uint(q3) & maskA), acc);
+                acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), q3, acc);
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[5], s), q2, acc);
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[6], s), q1, acc);
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[7], s), q0, acc);
@@ -352,7 +384,11 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         if (sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
     }
-    if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid);
+    // symmetric stage: 64 floats of +0 per wave in the gradient tile's space (every wave is past its last read of sG: the hash
+    // stage's last use of it lies before a workgroup barrier); written and read by the same wave, LDS operations of a wave run in order
+    float* zpad = reinterpret_cast<float*>(sG) + 64 * w;
+    if (SYM && PART != 1) zpad[lane] = 0.0f;
+    if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, zpad);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
     RAISR_PHASE(6);
 }
