@@ -112,6 +112,8 @@ struct ModelDev {
     _Float16* bank_mfma = nullptr;         // fast mode: binary16 B panels of k_filter_mfma, built on first use
     bool bank_mfma_valid = false;
     // symmetric filter stage (kernels_filter.h, filter_phase<.., SYM>): which bank rows are NOT palindromes
+    float* bank_lm = nullptr;              // lane-major copy of the blob's fp32 bank (k_lane_major_bank): what the filter stage reads
+    size_t bank_lm_bytes = 0;
     uint32_t* d_asym = nullptr;            // [32] bitmap over bucket * pixel_types + type (allocated with the first model)
     int asym_rows = -1;                    // number of set bits; -1 = not scanned (the symmetric kernel is never chosen then)
     // binary16 pipeline: thresholds folded onto the dividends of the hash's strength and coherence divisions (Pass16)
@@ -352,6 +354,7 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.qc0 = m.h.qcoh[0]; P.qc1 = m.h.qcoh[1];
     P.bank = (const float*)((const char*)m.blob + kBlobHeader);
     P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
+    P.bank_lm = m.bank_lm;
     P.tab14 = c->d_tab14;
     P.lut_legacy = c->d_lut;
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
@@ -816,6 +819,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     for (int i = 0; i < 2; i++) if (c->model[i].blob) (void)hipFree(c->model[i].blob);
     for (int i = 0; i < 2; i++) if (c->model[i].bank_mfma) (void)hipFree(c->model[i].bank_mfma);
     for (int i = 0; i < 2; i++) if (c->model[i].d_asym) (void)hipFree(c->model[i].d_asym);
+    for (int i = 0; i < 2; i++) if (c->model[i].bank_lm) (void)hipFree(c->model[i].bank_lm);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
@@ -903,6 +907,25 @@ static void fold16_thresholds(ModelDev& m)
     }
 }
 
+// The filter stage's copy of the fp32 bank (kernels_filter.h, k_lane_major_bank), rebuilt whenever a model arrives.
+static int build_lane_major_bank(raisr_hip_ctx* c, int pass_index)
+{
+    ModelDev& m = c->model[pass_index];
+    const int rows = m.h.hashkeys * m.h.pixel_types;
+    const size_t bytes = blob_f32_bytes(rows);
+    if (m.bank_lm && m.bank_lm_bytes != bytes) { (void)hipFree(m.bank_lm); m.bank_lm = nullptr; }
+    if (!m.bank_lm) {
+        if (hipMalloc((void**)&m.bank_lm, bytes) != hipSuccess) { m.bank_lm = nullptr; return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
+        m.bank_lm_bytes = bytes;
+    }
+    const unsigned n = (unsigned)rows * (unsigned)kTapsPad;
+    hipLaunchKernelGGL(k_lane_major_bank, dim3((n + 255u) / 256u), dim3(256), 0, c->stream,
+                       (const float*)((const char*)m.blob + kBlobHeader), m.bank_lm, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RAISR_HIP_OK;
+}
+
 // Which rows of the fp32 bank are palindromes (f[k] == f[120 - k], compared as bit patterns)?  Decides whether the symmetric
 // filter stage may run for this model and lists the rows whose pixels it has to redo with all eight coefficient loads.
 // `host_bank` = the blob's fp32 bank [rows][128] on the host, or null: then it is read back from the device blob.
@@ -974,6 +997,7 @@ int raisr_hip_set_model_blob_device(raisr_hip_ctx* c, int pass_index, const void
     HIP_TRY(hipStreamSynchronize(s));
     m.bytes = bytes; m.h = h; m.valid = true; m.bank_mfma_valid = false;
     fold16_thresholds(m);
+    if (int rc = build_lane_major_bank(c, pass_index)) return rc;
     if (int rc = scan_bank_symmetry(c, pass_index, nullptr)) return rc;
     return compute_zero_buckets(c, pass_index);
 }
@@ -1025,6 +1049,7 @@ int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int
     HIP_TRY(hipDeviceSynchronize());           // frames run on non-blocking streams, which nothing orders after a null-stream copy
     m.bytes = bytes; memcpy(&m.h, host.data(), sizeof m.h); m.valid = true; m.bank_mfma_valid = false;
     fold16_thresholds(m);
+    if (int rc = build_lane_major_bank(c, pass_index)) return rc;
     if (int rc = scan_bank_symmetry(c, pass_index, (const float*)(host.data() + kBlobHeader))) return rc;
     return compute_zero_buckets(c, pass_index);
 }

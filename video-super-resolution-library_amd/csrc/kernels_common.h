@@ -36,6 +36,8 @@ struct PassParams {
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)
+    const float* bank_lm;        // the bank once more, lane-major: row r = bucket * pixel_types + type holds, at float (ch >> 2) * 64 + l * 4 + (ch & 3),
+                                 // tap 16 ch + l -- the four (eight) coefficients of zmm lane l are one (two) 16-byte loads (k_lane_major_bank)
     const uint32_t* asym;        // symmetric filter stage (filter_phase<.., SYM>): bitmap [32 words] of the (bucket * pixel_types + type) bank rows
                                  // that are NOT palindromic (f[k] != f[120-k] somewhere), or null when every row is
     // frame batches (raisr_hip_process_y_device_batch): blockIdx.z = frame; plane f of a batch starts f * zs_* ELEMENTS after plane 0

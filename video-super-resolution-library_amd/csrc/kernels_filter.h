@@ -10,6 +10,17 @@
 // then sumitup_ps_512 as DPP row rotations by 8, 4, 2, 1.
 // Tile = 64 columns x 16 rows; wave w owns tile rows [4w, 4w+4); each step handles 4 adjacent pixels.
 // ------------------------------------------------------------------------------------------------
+// Lane-major copy of the fp32 bank (built once per model): the filter stage's lane l reads taps l, 16 + l, ..., 112 + l of a
+// row; stored next to each other, the four coefficients the symmetric stage needs are ONE 16-byte load per pixel step instead
+// of four 4-byte loads -- the same bytes through the vector L1 with a quarter of the load instructions.
+__global__ __launch_bounds__(256) void k_lane_major_bank(const float* __restrict__ bank, float* __restrict__ out, unsigned n)
+{
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n) return;
+    const unsigned r = e >> 7, k = e & 127u, ch = k >> 4, l = k & 15u;
+    out[r * 128u + (ch >> 2) * 64u + l * 4u + (ch & 3u)] = bank[e];
+}
+
 template <int CTRL>
 __device__ __forceinline__ float row_ror(float v)
 {
@@ -86,9 +97,12 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
     const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P.bank), 0, P.bank_bytes, 0x00020000);
+        const_cast<float*>(SYM ? P.bank_lm : P.bank), 0, P.bank_bytes, 0x00020000);
     const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
-    const unsigned lane_off = (unsigned)(tcol * kTapsPad + l) * 4u;   // byte offset of (type column part, zmm lane)
+    // byte offset of (type column part, zmm lane).  The symmetric stage reads the lane-major copy of the bank with one 16-byte load
+    // per step (C2 +1.2 % over four 4-byte loads); the eight-load stage stays on the natural layout: two 16-byte loads per step
+    // measured 4 % SLOWER than eight 4-byte loads (C1, C5, r04_call18) -- there the bytes through the vector L1 are what costs.
+    const unsigned lane_off = (unsigned)(tcol * kTapsPad + (SYM ? 4 * l : l)) * 4u;
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
@@ -110,6 +124,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #else
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
 #endif
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define RAISR_BANK_F4(voff) __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, (voff), 0, 0)      // lane-major bank: taps ch = 0..3 of the lane; + 256 B: ch = 4..7
 #define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
         // The plain 16-lane chains of one step with all eight loads (tail re-hash and, in the symmetric variant, the pixels of
         // non-palindromic rows).  The symmetric variant has no registers for the plain tap offsets: it recomputes them here, behind
@@ -122,6 +138,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
             } else {
+                const u32x4 fa = RAISR_BANK_F4(voff), fb = RAISR_BANK_F4(voff + 256u);
                 int lq = l;
                 asm volatile("" : "+v"(lq));
                 const float* base = sL + prow * LW + g + 4 * s;
@@ -130,7 +147,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
                 for (int ch = 0; ch < 8; ch++) {
                     const int k = 16 * ch + lq;
                     const float x = base[(k < kTaps) ? (k / 11) * LW + (k % 11) : 0];
-                    const float f = RAISR_BANK_F(voff + 64u * ch);
+                    const float f = __uint_as_float(ch < 4 ? fa[ch & 3] : fb[ch & 3]);
                     acc = ch == 0 ? x * f : __builtin_fmaf(x, f, acc);
                 }
             }
@@ -160,8 +177,14 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             float acc;
 #if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_COEF_REUSE)
             if (s % RAISR_EXP_COEF_REUSE == 0) {
+                if (SYM) {
+                    const u32x4 fa = RAISR_BANK_F4(voff);
 #pragma unroll
-                for (int ch = 0; ch < (SYM ? 4 : 8); ch++) qr[ch] = RAISR_BANK_F(voff + 64u * ch);
+                    for (int ch = 0; ch < 4; ch++) qr[ch] = __uint_as_float(fa[ch]);
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ch++) qr[ch] = RAISR_BANK_F(voff + 64u * ch);
+                }
             }
             if (!SYM) {
                 acc = RAISR_LDS_F(tap[0], s) * qr[0];
@@ -175,7 +198,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
             } else {
-                const float q0 = RAISR_BANK_F(voff), q1 = RAISR_BANK_F(voff + 64u), q2 = RAISR_BANK_F(voff + 128u), q3 = RAISR_BANK_F(voff + 192u);
+                const u32x4 fa = RAISR_BANK_F4(voff);
+                const float q0 = __uint_as_float(fa[0]), q1 = __uint_as_float(fa[1]), q2 = __uint_as_float(fa[2]), q3 = __uint_as_float(fa[3]);
 #endif
                 acc = RAISR_LDS_F(tap[0], s) * q0;
                 acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
@@ -243,6 +267,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             }
         }
 #undef RAISR_LDS_F
+#undef RAISR_BANK_F4
 #undef RAISR_BANK_F
         const int c = c0 + 4 * sl + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
