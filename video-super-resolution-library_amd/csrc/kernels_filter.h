@@ -168,6 +168,55 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // its sort, scattered window reads and scattered stores for free (docs/EXPERIMENTS.md I.4).
         float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if !defined(RAISR_EXP_COEF_REUSE) && !defined(RAISR_EXP_NO_WINDOW)
+#ifndef RAISR_EXP_PIPE
+#define RAISR_EXP_PIPE 1
+#endif
+        if (SYM) {
+            // The symmetric stage's steps, software-pipelined by hand in pairs of steps (a ds_read2_b32 fetches one tap of two
+            // steps): the coefficient load of pair p + 1 and its window reads are issued before the arithmetic of pair p, the
+            // bucket bytes one pair earlier still, with a scheduling fence per pair.  Against the compiler's own schedule (loads
+            // six steps ahead, window reads just in time): C2 +0.8 % with one or two pairs of look-ahead, +0 % with three
+            // (r04_call19).  Same operations on the same operands.
+            u32x4 Q[16];
+            float X[16][8];
+            unsigned Hh[16];
+            auto issue_h = [&](int s) { Hh[s] = sH[prow * TW + 4 * s + g]; };
+            auto issue_q = [&](int s) { Q[s] = RAISR_BANK_F4(__umul24(Hh[s], bank_stride) + row_lane_off); };
+            auto issue_x = [&](int s) {
+#pragma unroll
+                for (int ch = 0; ch < 8; ch++) X[s][ch] = RAISR_LDS_F(tap[ch], s);
+            };
+#pragma unroll
+            for (int s = 0; s < 16 && s < 2 * RAISR_EXP_PIPE + 2; s++) issue_h(s);
+#pragma unroll
+            for (int s = 0; s < 2 * RAISR_EXP_PIPE; s++) issue_q(s);
+            issue_x(0); issue_x(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                if (p + RAISR_EXP_PIPE < 8) { issue_q(2 * (p + RAISR_EXP_PIPE)); issue_q(2 * (p + RAISR_EXP_PIPE) + 1); }
+                if (p + RAISR_EXP_PIPE + 1 < 8) { issue_h(2 * (p + RAISR_EXP_PIPE + 1)); issue_h(2 * (p + RAISR_EXP_PIPE + 1) + 1); }
+                if (p + 1 < 8) { issue_x(2 * p + 2); issue_x(2 * p + 3); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 2 * p; s < 2 * p + 2; s++) {
+                    const float q0 = __uint_as_float(Q[s][0]), q1 = __uint_as_float(Q[s][1]), q2 = __uint_as_float(Q[s][2]), q3 = __uint_as_float(Q[s][3]);
+                    float acc = X[s][0] * q0;
+                    acc = __builtin_fmaf(X[s][1], q1, acc);
+                    acc = __builtin_fmaf(X[s][2], q2, acc);
+                    acc = __builtin_fmaf(X[s][3], q3, acc);
+                    acc = partner_xchg(acc);
+                    acc = __builtin_fmaf(X[s][4], q3, acc);
+                    acc = __builtin_fmaf(X[s][5], q2, acc);
+                    acc = __builtin_fmaf(X[s][6], q1, acc);
+                    acc = __builtin_fmaf(X[s][7], q0, acc);
+                    A16[s] = acc + row_ror<0x128>(acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#endif
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const unsigned hA = sH[prow * TW + 4 * s + g];
