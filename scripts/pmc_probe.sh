@@ -12,7 +12,7 @@ B="python $ROOT/bench.py --no-cpu-baseline --no-extras --no-kernel-timing --step
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_ANY" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/g$i" -- $B > "$OUT/g$i.log" 2>&1
 done

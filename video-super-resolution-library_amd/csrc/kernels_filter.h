@@ -468,7 +468,12 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
 }
 
 template <typename T, int PART = 0, int RPW = 4, bool SYM = false>
-__global__ __launch_bounds__(256, RPW == 4 ? 4 : 6) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
+#ifdef RAISR_EXP_OCC5
+#define RAISR_AC_WGS 5
+#else
+#define RAISR_AC_WGS 4
+#endif
+__global__ __launch_bounds__(256, RPW == 4 ? RAISR_AC_WGS : 6) void k_hashfilter_ac(const T* __restrict__ lr, PassParams P, GaussW gw, SepW S,
                                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr)
 {
     constexpr int TW = 64, TH = 4 * RPW;

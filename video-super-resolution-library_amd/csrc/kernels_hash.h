@@ -159,6 +159,18 @@ __device__ __forceinline__ void grad_products(const f2* p, float& pa, float& pb,
     pa = g.x * g.x; pb = g.x * g.y; pd = g.y * g.y;
 }
 template <typename T> struct GradOf { using type = f2; };
+#ifdef RAISR_EXP_OCC5            /* experiment: binary16 gradient tile for 8-bit samples (exact: |g| <= 255) + 88-entry worklist -> 32 768 B of LDS -> 5 workgroups per CU */
+typedef _Float16 gh2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 grad_load(const gh2* p) { const gh2 g = *p; return (f2){(float)g.x, (float)g.y}; }
+__device__ __forceinline__ void grad_store(gh2* p, float gx, float gy) { *p = (gh2){(_Float16)gx, (_Float16)gy}; }
+__device__ __forceinline__ void grad_products(const gh2* p, float& pa, float& pb, float& pd)
+{
+    const gh2 g = *p;
+    const float gx = (float)g.x, gy = (float)g.y;
+    pa = gx * gx; pb = gx * gy; pd = gy * gy;
+}
+template <> struct GradOf<uint8_t> { using type = gh2; };
+#endif
 
 
 
