@@ -422,8 +422,10 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
                           "frac": round(floor_ms / iso[dom], 4) if dom in iso else None,
                           "what": "vector-L1 delivery floor of the filter stage's coefficients / isolated launch of the dominant kernel (a floor, not the bound)"}
         if not fp16:
-            roofline["binding"] = ("issue / latency at 16 waves per CU: a wave issues one instruction per ~13 cycles, waits 38 % of its life on barriers and "
-                                   "LDS / L1 latency and 23 % for an issue slot (rocprofv3 SQ counters, docs/EXPERIMENTS.md I.1); fp32-valu utilisation is the figure to watch")
+            roofline["binding"] = ("instruction issue at 16 waves per CU with no pipe saturated: vector ALU ~55 % (at the 2.7 cycles per v_fma_f32 the part "
+                                   "sustains), LDS ~60 %, vector L1 ~40 % (~63 % for models whose bank is not symmetric) of the kernel's cycles; a fifth workgroup "
+                                   "per CU, prefetching and barrier removal change nothing, removing instructions does (rocprofv3 SQ counters and timing "
+                                   "probes, docs/EXPERIMENTS.md I.1, I.4); fp32-valu utilisation is the figure to watch")
     return roofline
 
 
