@@ -95,14 +95,12 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     // SYM: step 4 is tap 64 + l2 times c3 for l <= 8 and the padding step for l >= 9, whose window address points at zpad (64 floats
     // of +0 owned by this wave): p = +0 times c3 -- see the note on signed zeros above.
 
-    // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values)
-    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(SYM ? P.bank_lm : P.bank), 0, P.bank_bytes, 0x00020000);
+    // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values).  The stage reads the
+    // lane-major copy of the bank (k_lane_major_bank): the lane's coefficients of taps ch = 0..3 are one 16-byte load, ch = 4..7 the
+    // one 256 B further on.
+    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.bank_lm), 0, P.bank_bytes, 0x00020000);
     const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
-    // byte offset of (type column part, zmm lane).  The symmetric stage reads the lane-major copy of the bank with one 16-byte load
-    // per step (C2 +1.2 % over four 4-byte loads); the eight-load stage stays on the natural layout: two 16-byte loads per step
-    // measured 4 % SLOWER than eight 4-byte loads (C1, C5, r04_call18) -- there the bytes through the vector L1 are what costs.
-    const unsigned lane_off = (unsigned)(tcol * kTapsPad + (SYM ? 4 * l : l)) * 4u;
+    const unsigned lane_off = (unsigned)(tcol * kTapsPad + 4 * l) * 4u;      // byte offset of (type column part, zmm lane)
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
@@ -125,20 +123,19 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
 #endif
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define RAISR_BANK_F4(voff) __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, (voff), 0, 0)      // lane-major bank: taps ch = 0..3 of the lane; + 256 B: ch = 4..7
-#define RAISR_BANK_F(voff) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bank_rsrc, (voff), 0, 0))
-        // The plain 16-lane chains of one step with all eight loads (tail re-hash and, in the symmetric variant, the pixels of
+#define RAISR_BANK_F4(voff) __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, (voff), 0, 0)
+        // The plain 16-lane chains of one step with all eight coefficients (tail re-hash and, in the symmetric variant, the pixels of
         // non-palindromic rows).  The symmetric variant has no registers for the plain tap offsets: it recomputes them here, behind
         // an opaque lane index so that they are not hoisted into the main loop's live range.
         auto plain_step = [&](int s, unsigned hb) -> float {
             const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
+            const u32x4 fa = RAISR_BANK_F4(voff), fb = RAISR_BANK_F4(voff + 256u);
             float acc;
             if (!SYM) {
-                acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
+                acc = RAISR_LDS_F(tap[0], s) * __uint_as_float(fa[0]);
 #pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), __uint_as_float(ch < 4 ? fa[ch & 3] : fb[ch & 3]), acc);
             } else {
-                const u32x4 fa = RAISR_BANK_F4(voff), fb = RAISR_BANK_F4(voff + 256u);
                 int lq = l;
                 asm volatile("" : "+v"(lq));
                 const float* base = sL + prow * LW + g + 4 * s;
@@ -162,106 +159,89 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // bit).  Lane l ends up with the result of step sl = bitrev4(l): merge level 1 puts step bit 0 on lane bit 3, ..., level 4
         // step bit 3 on lane bit 0.
         float A16[16];
-#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_COEF_REUSE)
-        // TIMING PROBE, output wrong: coefficients are fetched for every RAISR_EXP_COEF_REUSE-th step only and reused for the steps
-        // between -- what any scheme that shares coefficient rows between pixels (key-chunked stage) could gain at most, with
-        // its sort, scattered window reads and scattered stores for free (docs/EXPERIMENTS.md I.4).
-        float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // One step: the lane's chain.  No branch for a bucket byte of 0xFF (pixel not filtered): its offset lies past the bank, the
+        // bounds-checked buffer loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
+        auto chain = [&](const float (&x)[8], const float (&q)[8]) -> float {
+            float acc = x[0] * q[0];
+            if (!SYM) {
+#pragma unroll
+                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(x[ch], q[ch], acc);
+            } else {                                            // q[0..3] only: the partner chain runs on the same four, backwards
+                acc = __builtin_fmaf(x[1], q[1], acc);
+                acc = __builtin_fmaf(x[2], q[2], acc);
+                acc = __builtin_fmaf(x[3], q[3], acc);
+                acc = partner_xchg(acc);
+                acc = __builtin_fmaf(x[4], q[3], acc);
+                acc = __builtin_fmaf(x[5], q[2], acc);
+                acc = __builtin_fmaf(x[6], q[1], acc);
+                acc = __builtin_fmaf(x[7], q[0], acc);
+            }
+            return acc + row_ror<0x128>(acc);                   // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
+        };
+        auto load_q = [&](unsigned hb, float (&q)[8]) {           // v_mad_u32_u24 for the offset (the 32x32 form is a slow 64-bit mad)
+            const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
+            const u32x4 fa = RAISR_BANK_F4(voff);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) q[ch] = __uint_as_float(fa[ch]);
+            if (!SYM) {
+                const u32x4 fb = RAISR_BANK_F4(voff + 256u);
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++) q[4 + ch] = __uint_as_float(fb[ch]);
+            }
+        };
+#if defined(RAISR_HIP_DEV) && (defined(RAISR_EXP_COEF_REUSE) || defined(RAISR_EXP_NO_WINDOW))
+        // TIMING PROBES, output wrong (docs/EXPERIMENTS.md I.4), on the compiler's own schedule.  RAISR_EXP_COEF_REUSE = n: coefficients
+        // are fetched for every n-th step only and reused for the steps between -- what any scheme that shares coefficient rows
+        // between pixels (key-chunked stage) could gain at most, with its sort, scattered window reads and scattered stores for free.
+#ifndef RAISR_EXP_COEF_REUSE
+#define RAISR_EXP_COEF_REUSE 1
 #endif
-#if !defined(RAISR_EXP_COEF_REUSE) && !defined(RAISR_EXP_NO_WINDOW)
-#ifndef RAISR_EXP_PIPE
-#define RAISR_EXP_PIPE 1
-#endif
-        if (SYM) {
-            // The symmetric stage's steps, software-pipelined by hand in pairs of steps (a ds_read2_b32 fetches one tap of two
-            // steps): the coefficient load of pair p + 1 and its window reads are issued before the arithmetic of pair p, the
-            // bucket bytes one pair earlier still, with a scheduling fence per pair.  Against the compiler's own schedule (loads
-            // six steps ahead, window reads just in time): C2 +0.8 % with one or two pairs of look-ahead, +0 % with three
-            // (r04_call19).  Same operations on the same operands.
-            u32x4 Q[16];
+        {
+            float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                if (s % RAISR_EXP_COEF_REUSE == 0) load_q(sH[prow * TW + 4 * s + g], qr);
+                float x[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ch++) x[ch] = RAISR_LDS_F(tap[ch], s);
+                A16[s] = chain(x, qr);
+            }
+        }
+#else
+        {
+            // The steps, software-pipelined by hand in pairs (a ds_read2_b32 fetches one tap of two steps): the coefficient loads and
+            // window reads of pair p + 1 are issued before the arithmetic of pair p, the bucket bytes one pair earlier still, with a
+            // scheduling fence per pair.  Against the compiler's own schedule (loads six steps ahead, window reads just in time):
+            // symmetric stage +0.8 % with one or two pairs of look-ahead, +0 % with three (r04_call19); the eight-load stage +1 %
+            // with 4-byte loads and +3.6-4.7 % with the two 16-byte loads (C1, C5; r04_call23), which on the compiler's schedule
+            // were 4 % SLOWER than eight 4-byte loads (r04_call18).  Same operations on the same operands.
+            constexpr int AHEAD = 1;
+            float Q[16][8];
             float X[16][8];
             unsigned Hh[16];
             auto issue_h = [&](int s) { Hh[s] = sH[prow * TW + 4 * s + g]; };
-            auto issue_q = [&](int s) { Q[s] = RAISR_BANK_F4(__umul24(Hh[s], bank_stride) + row_lane_off); };
             auto issue_x = [&](int s) {
 #pragma unroll
                 for (int ch = 0; ch < 8; ch++) X[s][ch] = RAISR_LDS_F(tap[ch], s);
             };
 #pragma unroll
-            for (int s = 0; s < 16 && s < 2 * RAISR_EXP_PIPE + 2; s++) issue_h(s);
+            for (int s = 0; s < 2 * AHEAD + 2; s++) issue_h(s);
 #pragma unroll
-            for (int s = 0; s < 2 * RAISR_EXP_PIPE; s++) issue_q(s);
+            for (int s = 0; s < 2 * AHEAD; s++) load_q(Hh[s], Q[s]);
             issue_x(0); issue_x(1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                if (p + RAISR_EXP_PIPE < 8) { issue_q(2 * (p + RAISR_EXP_PIPE)); issue_q(2 * (p + RAISR_EXP_PIPE) + 1); }
-                if (p + RAISR_EXP_PIPE + 1 < 8) { issue_h(2 * (p + RAISR_EXP_PIPE + 1)); issue_h(2 * (p + RAISR_EXP_PIPE + 1) + 1); }
+                if (p + AHEAD < 8) { load_q(Hh[2 * (p + AHEAD)], Q[2 * (p + AHEAD)]); load_q(Hh[2 * (p + AHEAD) + 1], Q[2 * (p + AHEAD) + 1]); }
+                if (p + AHEAD + 1 < 8) { issue_h(2 * (p + AHEAD + 1)); issue_h(2 * (p + AHEAD + 1) + 1); }
                 if (p + 1 < 8) { issue_x(2 * p + 2); issue_x(2 * p + 3); }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 2 * p; s < 2 * p + 2; s++) {
-                    const float q0 = __uint_as_float(Q[s][0]), q1 = __uint_as_float(Q[s][1]), q2 = __uint_as_float(Q[s][2]), q3 = __uint_as_float(Q[s][3]);
-                    float acc = X[s][0] * q0;
-                    acc = __builtin_fmaf(X[s][1], q1, acc);
-                    acc = __builtin_fmaf(X[s][2], q2, acc);
-                    acc = __builtin_fmaf(X[s][3], q3, acc);
-                    acc = partner_xchg(acc);
-                    acc = __builtin_fmaf(X[s][4], q3, acc);
-                    acc = __builtin_fmaf(X[s][5], q2, acc);
-                    acc = __builtin_fmaf(X[s][6], q1, acc);
-                    acc = __builtin_fmaf(X[s][7], q0, acc);
-                    A16[s] = acc + row_ror<0x128>(acc);
-                }
+                A16[2 * p] = chain(X[2 * p], Q[2 * p]);
+                A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else
-#endif
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const unsigned hA = sH[prow * TW + 4 * s + g];
-            // No branch for hA == 0xFF (pixel not filtered): its offset lies past the bank, the bounds-checked buffer
-            // loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
-            const unsigned voff = __umul24(hA, bank_stride) + row_lane_off;       // v_mad_u32_u24 (the 32x32 form is a slow 64-bit mad)
-            float acc;
-#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_COEF_REUSE)
-            if (s % RAISR_EXP_COEF_REUSE == 0) {
-                if (SYM) {
-                    const u32x4 fa = RAISR_BANK_F4(voff);
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++) qr[ch] = __uint_as_float(fa[ch]);
-                } else {
-#pragma unroll
-                    for (int ch = 0; ch < 8; ch++) qr[ch] = RAISR_BANK_F(voff + 64u * ch);
-                }
-            }
-            if (!SYM) {
-                acc = RAISR_LDS_F(tap[0], s) * qr[0];
-#pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), qr[ch], acc);
-            } else {
-                const float q0 = qr[0], q1 = qr[1], q2 = qr[2], q3 = qr[3];
-#else
-            if (!SYM) {
-                acc = RAISR_LDS_F(tap[0], s) * RAISR_BANK_F(voff);
-#pragma unroll
-                for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(RAISR_LDS_F(tap[ch], s), RAISR_BANK_F(voff + 64u * ch), acc);
-            } else {
-                const u32x4 fa = RAISR_BANK_F4(voff);
-                const float q0 = __uint_as_float(fa[0]), q1 = __uint_as_float(fa[1]), q2 = __uint_as_float(fa[2]), q3 = __uint_as_float(fa[3]);
-#endif
-                acc = RAISR_LDS_F(tap[0], s) * q0;
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[1], s), q1, acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[2], s), q2, acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[3], s), q3, acc);
-                acc = partner_xchg(acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[4], s), q3, acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[5], s), q2, acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[6], s), q1, acc);
-                acc = __builtin_fmaf(RAISR_LDS_F(tap[7], s), q0, acc);
-            }
-            A16[s] = acc + row_ror<0x128>(acc);                // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
         }
+#endif
 #define RAISR_MERGE(dst, src, mask) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask))
         float B8[8], C4[4], D2[2];
 #pragma unroll
@@ -317,7 +297,6 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         }
 #undef RAISR_LDS_F
 #undef RAISR_BANK_F4
-#undef RAISR_BANK_F
         const int c = c0 + 4 * sl + g;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
