@@ -634,6 +634,9 @@ def config_leg(R, torch, name, gpu, load_blobs, lanes_n, n_frames, fence, kind, 
     b = load_blobs(w)
     frames = w.frames(kind, range(8 if w.out_w <= 3840 else 4))
     batch = batch or auto_batch(w)
+    # small outputs: more frames, so that every configuration's timed loop covers about the pixel volume of the 4K legs (a
+    # 256-frame loop of 1080p outputs lasts 11 ms: start-up and tail of 4 lanes x 8 launches weigh 10 % there)
+    n_frames *= max(1, (3840 * 2160) // (w.out_w * w.out_h))
     n_frames = max(batch, n_frames // batch * batch)
     dt, kern, lanes, d_in, d_out = device_loop(R, torch, w, gpu, b, lanes_n, frames, n_frames, 1, 1, fence, True, batch=batch)
     iso = isolated_kernel_ms(lanes, d_in, d_out, w, torch, iters=12)
