@@ -156,3 +156,18 @@ def test_shared_tree_of_sixteen_steps_gives_each_lane_its_step():
     for l in lanes:
         sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3)
         assert v[l].view(np.uint32) == want[sl].view(np.uint32), (l, sl)
+
+
+def test_lane_major_bank_layout_feeds_each_lane_its_chain():
+    """k_lane_major_bank (csrc/kernels_filter.h) permutes every 128-float bank row so that zmm lane l finds taps l, 16 + l, ..., 112 + l
+    as two runs of four floats: float (ch >> 2) * 64 + 4 l + (ch & 3) holds tap 16 ch + l.  The filter stage reads run 0 (and run 1,
+    256 B further on, in the eight-load stage) with one 16-byte load each."""
+    row = np.arange(128, dtype=np.int32)                                   # tap index as the value
+    out = np.empty_like(row)
+    for e in range(128):                                                   # the kernel's index arithmetic
+        ch, l = e >> 4, e & 15
+        out[(ch >> 2) * 64 + l * 4 + (ch & 3)] = row[e]
+    for l in range(16):
+        assert list(out[4 * l:4 * l + 4]) == [16 * c + l for c in range(4)]
+        assert list(out[64 + 4 * l:64 + 4 * l + 4]) == [16 * c + l for c in range(4, 8)]
+    assert sorted(out) == list(range(128))                                 # a permutation: nothing lost, padding taps 121..127 included
