@@ -56,8 +56,16 @@ RNLERRORTYPE RNLHandler_Deinit(void);
  *   FramesInFlight()   submitted and not yet collected
  * Deinit waits for the frames in flight and drops them; SetRes refuses (RNLErrorBadParameter) while frames are in flight:
  * collect them first.  Not available with asm = HIPExternal (device frames are stream-ordered).
+ *   SetDeviceList("0,1,2,3" | "all" | "")   SEVERAL GPUs behind one handler: the asynchronous ring gets `depth` lanes on every
+ *                      listed device, frame i runs on device i mod n, Collect keeps submission order -- one FFmpeg process
+ *                      feeds the whole node (the reference reaches its socket numbers with N processes, docs/performance.md:8-13).
+ *                      "" = the single device of SetOpenCLContext / RAISR_HIP_DEVICE again.  Without a call the environment
+ *                      variable RAISR_HIP_DEVICES (same syntax) is honoured.  Call after Init with nothing in flight;
+ *                      RNLErrorBadParameter for a malformed list or a device the runtime does not have.  Process (synchronous)
+ *                      keeps running on the first device.
  */
 RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth);
+RNLERRORTYPE RNLHandler_SetDeviceList(const char *devices);
 RNLERRORTYPE RNLHandler_Submit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
                                VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb,
                                BlendingMode blend);

@@ -90,6 +90,10 @@ int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const
  * collective; librccl.so is loaded on first use, so single-GPU consumers carry no RCCL dependency.  The reference is a CPU
  * library and has no counterpart; bench.py / sharding.py issue the same broadcast through torch.distributed. */
 int    raisr_hip_broadcast_model_blob(void *nccl_comm, int root, void *device_blob, size_t bytes, void *stream);
+/* One process, several GPUs (raisr_hip_stream_create_multi): blobs[0] (on devices[0]) holds the packed model, blobs[i] (on
+ * devices[i]) receives it -- one in-process RCCL communicator per device and a grouped broadcast over xGMI when the devices are
+ * distinct, device / peer copies when a device is listed twice, RAISR_HIP_NO_RCCL=1 is set or librccl is absent.  Synchronous. */
+int    raisr_hip_broadcast_model_blob_devices(const int *devices, int n, void *const *device_blobs, size_t bytes);
 
 /* Geometry / resources ------------------------------------------------------------------------ */
 int raisr_hip_configure(raisr_hip_ctx *ctx, const raisr_hip_config *cfg);
@@ -204,6 +208,25 @@ int  raisr_hip_set_after(raisr_hip_ctx *ctx, raisr_hip_ctx *prev);   /* bands of
 typedef struct raisr_hip_stream raisr_hip_stream;
 #define RAISR_HIP_STREAM_MAX_DEPTH 4                                                    /* frames in flight per ring: more never measured faster */
 int  raisr_hip_stream_create(raisr_hip_stream **out, int device_index, int depth);     /* depth 1..RAISR_HIP_STREAM_MAX_DEPTH, else RAISR_HIP_EINVAL */
+/* The same ring over SEVERAL GPUs from one host thread (north_star: "host code stays C++ ... frames shard across the 8 GPUs";
+ * the reference reaches its socket numbers only with N processes, docs/performance.md:8-13): n devices x depth lanes, frame i
+ * runs on devices[i % n] (lane (i / n) % depth of that device), collect() returns frames in submission order.  Every device has
+ * its own lanes, streams, scratch planes and page-locked bounce memory; raisr_hip_stream_set_model() packs the model ONCE,
+ * uploads it to devices[0] and hands it to the others with raisr_hip_broadcast_model_blob_devices().  A device may be listed
+ * more than once (tests; two rings' worth of lanes on one GPU).  n = 1..RAISR_HIP_STREAM_MAX_DEVICES, depth as above;
+ * raisr_hip_stream_depth() = n * depth frames in flight.  Frame planes must be page-locked memory every listed device can
+ * reach (raisr_hip_host_alloc allocates it so) or pageable memory. */
+#define RAISR_HIP_STREAM_MAX_DEVICES 16
+int  raisr_hip_stream_create_multi(raisr_hip_stream **out, const int *devices, int n, int depth);
+int  raisr_hip_stream_device_count(const raisr_hip_stream *s);                         /* n of create_multi (1 for raisr_hip_stream_create) */
+int  raisr_hip_stream_device_of_frame(const raisr_hip_stream *s, unsigned long long frame_index);   /* devices[frame_index % n] */
+/* "0,2,3" / "all" / "" -> device list (what RAISR_HIP_DEVICES and the plugin's device option carry); returns the count written
+ * (<= max), 0 for an empty string, -1 for a malformed one or an index the runtime does not have. */
+int  raisr_hip_parse_device_list(const char *text, int *devices, int max);
+int  raisr_hip_parse_device_list_n(const char *text, int devices_present, int *devices, int max);   /* the same against a given device count (no runtime call) */
+/* The ring's frame order as a pure function: frame_index runs on device slot frame_index % n_devices, on that device's lane
+ * (frame_index / n_devices) % depth -- what submit() and collect() walk. */
+void raisr_hip_ring_slot(int n_devices, int depth, unsigned long long frame_index, int *device_slot, int *lane_on_device);
 void raisr_hip_stream_destroy(raisr_hip_stream *s);
 int  raisr_hip_stream_depth(const raisr_hip_stream *s);
 int  raisr_hip_stream_set_model(raisr_hip_stream *s, int pass_index, const float *bank, int hashkeys, int pixel_types,

@@ -289,6 +289,11 @@ def test_hipexternal_device_planes_against_the_oracle(bits, passes, use_stream, 
     ou = torch.zeros((h, w + 16), dtype=tdt, device="cuda")
     ov = torch.zeros((h, w + 16), dtype=tdt, device="cuda")
     ds = [vdt(dy, w, h), vdt(du, w // 2, h // 2), vdt(dv, w // 2, h // 2), vdt(oy, 2 * w, 2 * h), vdt(ou, w, h), vdt(ov, w, h)]
+    if use_stream:
+        # the reference reads bitShift from the INPUT descriptors only (Raisr.cpp:1313-1348): a caller that leaves the output
+        # descriptors' field at 0 is served with the input's alignment
+        for d in ds[3:]:
+            d.bitShift = 0
     refs = [ctypes.byref(x) for x in ds]
     stream = torch.cuda.Stream() if use_stream else None
     assert R.RNLHandler_SetOpenCLContext(0, 0, stream.cuda_stream if stream else None) == 0

@@ -1,0 +1,154 @@
+"""-m gpu: the multi-device stream ring (raisr_hip_stream_create_multi) and its plugin-API face (RNLHandler_SetDeviceList /
+RAISR_HIP_DEVICES) -- one host thread, frame i on device slot i % n, in-order collection.  The GPU box has ONE device, so the
+device list names it several times: every slot still has its own lanes, streams, scratch planes and bounce memory, the model
+still reaches the slots through raisr_hip_broadcast_model_blob_devices (copy fall-back: RCCL wants distinct devices), and every
+frame must equal the oracle's, in order.  (north_star: "host code stays C++ ... frames shard across the 8 GPUs".)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from common import folder, oracle_y
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices,depth", [([0], 2), ([0, 0], 2), ([0, 0, 0], 1), ([0, 0, 0, 0], 4)])
+@pytest.mark.parametrize("pinned", [True, False])
+def test_600_frame_c5_shaped_stream_over_a_device_list(devices, depth, pinned):
+    """C5's shape (2x, highres, 10-bit, yuv420p) at 480 x 270 -> 960 x 540, 600 frames cycling over 5 distinct inputs."""
+    import oracle_py as O
+    import raisr_hip as R
+    import synth
+    w, h, bits, n, uniq = 480, 270, 10, 600, 5
+    fold = "filters_2x/filters_highres"
+    case = ("x", fold, (2, 1), bits, 1, 1, 2, False)
+    ys = [synth.natural_y(w, h, bits, seed=500 + i) for i in range(uniq)]
+    refs = [oracle_y(y, case) for y in ys]
+    cin = synth.random_y(w // 2, h // 2, bits, seed=9).astype(np.uint16)
+    cref = O.resize(cin, w, h).astype(np.uint16)
+    pins = []
+
+    def plane(shape, fill=None):
+        if pinned:
+            pl = R.PinnedPlane(shape, np.uint16); pins.append(pl); a = pl.array
+        else:
+            a = np.zeros(shape, np.uint16)
+        if fill is not None:
+            a[...] = fill
+        return a
+    st = R.RaisrStream(devices, folder(fold), w, h, 2 * w, 2 * h, bits=bits, chroma=(w // 2, h // 2, w, h), depth=depth)
+    cap = st.depth
+    assert cap == len(devices) * depth
+    assert R.lib().raisr_hip_stream_device_count(st._h) == len(devices)
+    assert [R.lib().raisr_hip_stream_device_of_frame(st._h, i) for i in range(7)] == [devices[i % len(devices)] for i in range(7)]
+    yin = [plane((h, w), y) for y in ys]
+    c = plane((h // 2, w // 2), cin)
+    outs = [(plane((2 * h, 2 * w)), plane((h, w)), plane((h, w))) for _ in range(cap)]
+    bad = []
+    try:
+        done = inflight = 0
+
+        def collect():
+            nonlocal done, inflight
+            st.collect()
+            oy, ou, ov = outs[done % cap]
+            if not np.array_equal(oy, refs[done % uniq]) or not np.array_equal(ou, cref) or not np.array_equal(ov, cref):
+                bad.append(done)
+            oy[0, :8] = 0; ou[0, :8] = 0                       # stale bytes must not survive into the lane's next frame
+            done += 1; inflight -= 1
+        for i in range(n):
+            if inflight == cap:
+                with pytest.raises(RuntimeError):
+                    st.submit(yin[0], c, c, *outs[0])          # ring full: collect first
+                collect()
+            st.submit(yin[i % uniq], c, c, *outs[i % cap])
+            inflight += 1
+        while inflight:
+            collect()
+    finally:
+        st.close()
+        for pl in pins:
+            pl.close()
+    assert done == n and not bad, bad[:10]
+
+
+def test_create_multi_argument_checks():
+    import raisr_hip as R
+    h = ctypes.c_void_p()
+    L = R.lib()
+    one = (ctypes.c_int * 1)(0)
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), one, 0, 2) != 0
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), one, 1, 5) != 0                     # lanes per device: 1..4
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), None, 1, 2) != 0
+    many = (ctypes.c_int * 17)(*([0] * 17))
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), many, 17, 1) != 0
+    gone = (ctypes.c_int * 2)(0, 99)
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), gone, 2, 1) != 0                    # no such device: nothing leaks, nothing half-built
+    assert not h.value
+
+
+@pytest.mark.parametrize("how", ["call", "env"])
+def test_plugin_api_ring_over_a_device_list(how, monkeypatch):
+    """RNLHandler_SetDeviceList("0,0") / RAISR_HIP_DEVICES=0,0 + SetAsyncDepth(2): four frames in flight over two device slots, the
+    FFmpeg filter's call sequence with async=2, every collected frame the oracle's, in order."""
+    import raisr_hip as R
+    import synth
+    w, h, bits, n = 176, 100, 8, 23
+    fold = "filters_2x/filters_highres"
+    ys = [synth.natural_y(w, h, bits, seed=700 + s) for s in range(n)]
+    us = [synth.random_y(w // 2, h // 2, bits, seed=800 + s).astype(np.uint8) for s in range(n)]
+    refs = [oracle_y(y, ("x", fold, (2, 1), bits, 1, 1, 2, False)) for y in ys]
+    outs = [(np.zeros((2 * h, 2 * w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)) for _ in range(n)]
+    if how == "env":
+        monkeypatch.setenv("RAISR_HIP_DEVICES", "0,0")
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder(fold), 2.0, bits, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        assert R.RNLHandler_SetRes((ys[0], us[0], us[0]), outs[0]) == 0
+        assert R.RNLHandler_SetDeviceList("0,7") == R.RNLErrorBadParameter                      # no device 7 on this box
+        assert R.RNLHandler_SetDeviceList("0;0") == R.RNLErrorBadParameter
+        if how == "call":
+            assert R.RNLHandler_SetDeviceList("0,0") == 0
+        assert R.RNLHandler_SetAsyncDepth(2) == 0
+        inflight = done = 0
+        for i in range(n):
+            if inflight == 4:                                                                     # 2 device slots x depth 2
+                assert R.RNLHandler_Submit((ys[i], us[i], us[i]), outs[i]) == R.RNLErrorInsufficientResources
+                assert R.RNLHandler_Collect() == 0
+                assert np.array_equal(outs[done][0], refs[done]), done
+                done += 1; inflight -= 1
+            assert R.RNLHandler_Submit((ys[i], us[i], us[i]), outs[i]) == 0
+            inflight += 1
+            if i == 5:
+                assert R.RNLHandler_SetDeviceList("0") == R.RNLErrorBadParameter                  # frames in flight: collect first
+        while inflight:
+            assert R.RNLHandler_Collect() == 0
+            assert np.array_equal(outs[done][0], refs[done]), done
+            done += 1; inflight -= 1
+        assert done == n
+        assert R.RNLHandler_SetDeviceList("") == 0                                                # back to the single device
+        assert R.RNLHandler_Submit((ys[0], us[0], us[0]), outs[0]) == 0
+        assert R.RNLHandler_Submit((ys[1], us[1], us[1]), outs[1]) == 0
+        assert R.RNLHandler_Submit((ys[2], us[2], us[2]), outs[2]) == R.RNLErrorInsufficientResources
+        assert R.RNLHandler_Collect() == 0 and R.RNLHandler_Collect() == 0
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+
+
+def test_blob_broadcast_over_a_device_list_copies_the_blob():
+    """raisr_hip_broadcast_model_blob_devices with a repeated device (the copy fall-back) and with RAISR_HIP_NO_RCCL semantics:
+    every destination ends up with the source's bytes."""
+    import raisr_hip as R
+    import torch
+    bank, qstr, qcoh, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, 1)
+    blob = R.pack_model_blob(bank, qstr, qcoh, qa)
+    src = torch.from_numpy(blob).cuda()
+    dsts = [torch.zeros_like(src) for _ in range(3)]
+    devs = (ctypes.c_int * 4)(0, 0, 0, 0)
+    ptrs = (ctypes.c_void_p * 4)(src.data_ptr(), *[d.data_ptr() for d in dsts])
+    assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 4, ptrs, blob.size) == 0
+    torch.cuda.synchronize()
+    for d in dsts:
+        assert torch.equal(d, src)
+    assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 0, ptrs, blob.size) != 0

@@ -33,6 +33,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -57,6 +58,7 @@ namespace {
 #include "kernels_hash_certify.h"    // approx_hash, tensor_ac, hash_phase_ac
 #include "kernels_fp16.h"            // binary16 pipeline: k_hashfilter16, k_hash16, k_filter16, k_blend16
 #include "kernels_filter.h"          // filter_phase, k_filter, k_hashfilter, k_hashfilter_ac
+#include "kernels_fix.h"             // k_fix_ac: deferred exact path of k_hashfilter_ac
 #ifdef RAISR_HIP_DEV
 #include "kernels_experiments.h"     // persistent-grid variant of k_hashfilter_ac (-DRAISR_EXP_PERSIST)
 #endif
@@ -227,8 +229,11 @@ struct raisr_hip_ctx {
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
-    int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
+    int sym_max_rows = -1;                     // ... chosen when at most this many rows are not (-1: a fifth of the bank's rows; RAISR_HIP_SYM_MAX_ROWS for A/B runs);
+                                               // a pixel step that meets one of them fetches the partner block as well (kernels_filter.h)
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
+    bool defer = true;                         // uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist (RAISR_HIP_DEFER=0: in-tile)
+    FixAc fixac{};                             // ... the list (sized at configure: tiles of the largest pass x batch depth)
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     int fast = 0;                              // NON-bit-exact fast mode (raisr_hip_set_fast / RAISR_HIP_FAST): 1 = exact buckets, filter stage on the matrix cores; 2 = also keeps the approximate tensor's bucket where it is not certified
     bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
@@ -378,7 +383,7 @@ bool launch_dev_variant(raisr_hip_ctx* c, hipStream_t s, int pass, const void* l
 {
     static const int part = getenv("RAISR_HIP_AC_PART") ? atoi(getenv("RAISR_HIP_AC_PART")) : 0;
     if (part == 2 && getenv("RAISR_HIP_AC_PATTERN")) P.cert_check = atoi(getenv("RAISR_HIP_AC_PATTERN"));
-    if (part == 1) { hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]); return true; }
+    if (part == 1) { hipLaunchKernelGGL((k_hashfilter_ac<TOut, 1>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{}); return true; }
     if (part == 2) {
         if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2, 4, true>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
         else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 2>), gf, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
@@ -405,6 +410,33 @@ bool launch_dev_variant(raisr_hip_ctx* c, hipStream_t s, int pass, const void* l
 }
 #endif
 
+// The production kernel of the fp32 numerics on a grid of tiles (whole plane x frames of a batch, or a range of tile rows starting
+// at P.tile_y0), followed -- deferred exact path -- by k_fix_ac on the same tiles.  The self-check mode (cert_check: every pixel also
+// takes the exact path) and RAISR_HIP_DEFER=0 use the in-tile worklist variant.
+template <typename TOut>
+void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void* lrp, const PassParams& P, dim3 grid, bool sym, dim3 plane_tiles)
+{
+    int slot;
+    if (c->defer && !P.cert_check) {
+        FixAc F = c->fixac;
+        F.tiles_x = (int)plane_tiles.x;
+        F.zs_tiles = plane_tiles.x * plane_tiles.y;
+        timer_begin(c, "k_hashfilter_ac", s, slot);
+        if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], F);
+        else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, false, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], F);
+        timer_end(c, s, slot);
+        const unsigned tile_first = (unsigned)P.tile_y0 * plane_tiles.x, tile_count = grid.x * grid.y;
+        timer_begin(c, "k_fix_ac", s, slot);
+        hipLaunchKernelGGL((k_fix_ac<TOut>), dim3((tile_count + 3u) / 4u, 1, grid.z), dim3(256), 0, s, (const TOut*)lrp, P, F, c->d_hash[pass], c->d_hr[pass], tile_first, tile_count);
+        timer_end(c, s, slot);
+        return;
+    }
+    timer_begin(c, "k_hashfilter_ac", s, slot);
+    if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
+    else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
+    timer_end(c, s, slot);
+}
+
 // frame batches: plane strides of this pass's launches (0 for a single frame); zs_out = stride of `out`'s planes
 void batch_strides(const raisr_hip_ctx* c, int pass, size_t zs_out, PassParams& P)
 {
@@ -430,7 +462,8 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
         const int asym_rows = c->model[pass].asym_rows;
-        const bool sym = c->sym && asym_rows >= 0 && asym_rows <= c->sym_max_rows;   // symmetric filter stage of k_hashfilter_ac
+        const int sym_rows_max = c->sym_max_rows >= 0 ? c->sym_max_rows : c->model[pass].h.hashkeys * c->model[pass].h.pixel_types / 5;
+        const bool sym = c->sym && asym_rows >= 0 && asym_rows <= sym_rows_max;   // symmetric filter stage of k_hashfilter_ac
         if (c->fast || (c->fused && c->certify && c->split)) {
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
@@ -499,10 +532,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 const int t0 = (int)((long long)Ty * i / nchunks), t1 = (int)((long long)Ty * (i + 1) / nchunks);
                 const int b1 = i == nchunks - 1 ? Tb : t1;
                 P.tile_y0 = t0;
-                timer_begin(c, "k_hashfilter_ac", s, slot);
-                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, (unsigned)(t1 - t0)), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                timer_end(c, s, slot);
+                launch_hashfilter_ac<TOut>(c, s, pass, lrp, P, dim3(gf.x, (unsigned)(t1 - t0)), sym, gf);
                 timer_begin(c, "k_blend", s, slot);
                 hipLaunchKernelGGL((k_blend<TOut>), dim3((W + 63) / 64, (unsigned)(b1 - t0)), dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
                 timer_end(c, s, slot);
@@ -514,13 +544,13 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
             P.write_hash = c->keep_hash_plane;
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
-            timer_begin(c, "k_hashfilter_ac", s, slot);
 #ifdef RAISR_HIP_DEV
-            if (launch_dev_variant<TOut>(c, s, pass, lrp, P, gf, H, sym)) {} else
-#endif
-                if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
-                else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), dim3(gf.x, gf.y, nz), dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass]);
+            timer_begin(c, "k_hashfilter_ac", s, slot);
+            const bool dev_taken = launch_dev_variant<TOut>(c, s, pass, lrp, P, gf, H, sym);
             timer_end(c, s, slot);
+            if (!dev_taken)
+#endif
+            launch_hashfilter_ac<TOut>(c, s, pass, lrp, P, dim3(gf.x, gf.y, nz), sym, gf);
         } else if (c->fused) {
             P.write_hash = c->keep_hash_plane;
             timer_begin(c, "k_hashfilter", s, slot);
@@ -638,6 +668,9 @@ void free_scratch(raisr_hip_ctx* c)
     if (c->fix.sparse) (void)hipFree(c->fix.sparse);
     if (c->fix.dense) (void)hipFree(c->fix.dense);
     if (c->fix.cert_mask) (void)hipFree(c->fix.cert_mask);
+    if (c->fixac.counts) (void)hipFree(c->fixac.counts);
+    if (c->fixac.entries) (void)hipFree(c->fixac.entries);
+    c->fixac = FixAc{};
     c->fix = FixLists{};
     c->fix_tiles = 0;
 }
@@ -724,6 +757,7 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
+    if (const char* e = getenv("RAISR_HIP_DEFER")) c->defer = atoi(e) != 0;       // A/B switch: 0 = in-tile worklist instead of k_fix_ac
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
@@ -912,13 +946,13 @@ static int build_lane_major_bank(raisr_hip_ctx* c, int pass_index)
 {
     ModelDev& m = c->model[pass_index];
     const int rows = m.h.hashkeys * m.h.pixel_types;
-    const size_t bytes = blob_f32_bytes(rows);
+    const size_t bytes = (size_t)rows * kLmRow * sizeof(float);
     if (m.bank_lm && m.bank_lm_bytes != bytes) { (void)hipFree(m.bank_lm); m.bank_lm = nullptr; }
     if (!m.bank_lm) {
         if (hipMalloc((void**)&m.bank_lm, bytes) != hipSuccess) { m.bank_lm = nullptr; return fail(RAISR_HIP_ENOMEM, "hipMalloc"); }
         m.bank_lm_bytes = bytes;
     }
-    const unsigned n = (unsigned)rows * (unsigned)kTapsPad;
+    const unsigned n = (unsigned)rows * kLmRow;
     hipLaunchKernelGGL(k_lane_major_bank, dim3((n + 255u) / 256u), dim3(256), 0, c->stream,
                        (const float*)((const char*)m.blob + kBlobHeader), m.bank_lm, n);
     HIP_TRY(hipGetLastError());
@@ -1032,6 +1066,72 @@ int raisr_hip_broadcast_model_blob(void* nccl_comm, int root, void* device_blob,
     return RAISR_HIP_OK;
 }
 
+// In-process counterpart for ONE host process driving several GPUs (raisr_hip_stream_create_multi): blobs[0] on devices[0]
+// holds the packed model; blobs[i] on devices[i] receives it.  Distinct devices: one RCCL communicator per device
+// (ncclCommInitAll) and a grouped ncclBroadcast -- the filter bank crosses xGMI once per device and never the PCIe bus again.
+// A device listed more than once (one GPU standing in for several: tests, oversubscription), RAISR_HIP_NO_RCCL=1 or a missing
+// librccl: plain device / peer copies.
+int raisr_hip_broadcast_model_blob_devices(const int* devices, int n, void* const* blobs, size_t bytes)
+{
+    if (!devices || !blobs || n < 1 || bytes < (size_t)kBlobHeader) return fail(RAISR_HIP_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) if (!blobs[i] || devices[i] < 0) return fail(RAISR_HIP_EINVAL, "bad argument");
+    if (n == 1) return RAISR_HIP_OK;
+    bool distinct = true;
+    for (int i = 0; i < n && distinct; i++)
+        for (int k = 0; k < i; k++) if (devices[k] == devices[i]) { distinct = false; break; }
+    const char* no = getenv("RAISR_HIP_NO_RCCL");
+    bool done = false;
+    if (distinct && !(no && atoi(no) != 0)) {
+        typedef int (*initall_fn)(void**, int, const int*);
+        typedef int (*group_fn)(void);
+        typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+        typedef int (*destroy_fn)(void*);
+        static std::mutex mu;
+        static initall_fn initall = nullptr; static group_fn gstart = nullptr, gend = nullptr; static bcast_fn bcast = nullptr; static destroy_fn destroy = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!initall) {
+                void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    gstart = reinterpret_cast<group_fn>(dlsym(h, "ncclGroupStart"));
+                    gend = reinterpret_cast<group_fn>(dlsym(h, "ncclGroupEnd"));
+                    bcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
+                    destroy = reinterpret_cast<destroy_fn>(dlsym(h, "ncclCommDestroy"));
+                    initall = reinterpret_cast<initall_fn>(dlsym(h, "ncclCommInitAll"));
+                    if (!gstart || !gend || !bcast || !destroy) initall = nullptr;
+                }
+            }
+        }
+        if (initall) {
+            std::vector<void*> comms((size_t)n, nullptr);
+            if (initall(comms.data(), n, devices) == 0) {
+                const int kNcclUint8 = 1;
+                bool ok = gstart() == 0;
+                for (int i = 0; i < n && ok; i++) {
+                    ok = hipSetDevice(devices[i]) == hipSuccess &&
+                         bcast(blobs[i], blobs[i], bytes, kNcclUint8, 0, comms[(size_t)i], (hipStream_t) nullptr) == 0;
+                }
+                ok = (gend() == 0) && ok;
+                for (int i = 0; i < n; i++) { if (hipSetDevice(devices[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) ok = false; }
+                for (void* cm : comms) if (cm) (void)destroy(cm);
+                if (!ok) return fail(RAISR_HIP_ERUNTIME, "in-process RCCL broadcast of the model blob failed");
+                done = true;
+            } else (void)hipGetLastError();                      // no communicator (e.g. one visible GPU under a restrictive runtime): copies below
+        }
+    }
+    if (!done) {
+        for (int i = 1; i < n; i++) {
+            if (blobs[i] == blobs[0]) continue;
+            if (devices[i] == devices[0]) { HIP_TRY(hipSetDevice(devices[0])); HIP_TRY(hipMemcpy(blobs[i], blobs[0], bytes, hipMemcpyDeviceToDevice)); }
+            else HIP_TRY(hipMemcpyPeer(blobs[i], devices[i], blobs[0], devices[0], bytes));
+        }
+        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return RAISR_HIP_OK;
+}
+
 int raisr_hip_set_model(raisr_hip_ctx* c, int pass_index, const float* bank, int hashkeys, int pixel_types,
                         const double qstr[2], const double qcoh[2], int quant_angle)
 {
@@ -1117,6 +1217,8 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
     for (int p = 0; p < cfg->passes; p++)
         if (c->model[p].h.pixel_types != (cfg->use_pixel_type ? 4 : 1))
             return fail(RAISR_HIP_EINVAL, "model pixel types do not match ratio");
+    if (c->sample_shift && cfg->bits + c->sample_shift > (cfg->bits == 8 ? 8 : 16))      // set before this configure: checked against the new sample size
+        return fail(RAISR_HIP_EINVAL, "the sample shift set on this context does not fit the configured sample size");
     if (c->fast && !fast_mode_supported(cfg))
         return fail(RAISR_HIP_EINVAL, "fast mode (matrix-core filter stage) supports ratio 2, 8/10-bit content and the fp32 flavours only");
     HIP_TRY(hipSetDevice(c->device));
@@ -1158,6 +1260,13 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
             return fail(RAISR_HIP_ENOMEM, "worklist alloc");
         }
         HIP_TRY(hipMemsetAsync(c->fix.counters, 0, 2 * sizeof(unsigned), c->stream));
+        // list of the deferred exact path (k_hashfilter_ac<.., DEFER> -> k_fix_ac): one region of kWaveCap entries per (tile, wave)
+        if (hipMalloc((void**)&c->fixac.counts, cap * tiles * 4) != hipSuccess ||
+            hipMalloc((void**)&c->fixac.entries, cap * tiles * 4 * kWaveCap * sizeof(uint16_t)) != hipSuccess) {
+            free_scratch(c);
+            return fail(RAISR_HIP_ENOMEM, "fix list alloc");
+        }
+        HIP_TRY(hipMemsetAsync(c->fixac.counts, 0, cap * tiles * 4, c->stream));
     }
     if (cfg->passes == 2) {
         // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
@@ -1188,7 +1297,9 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
 int raisr_hip_set_sample_shift(raisr_hip_ctx* c, int shift)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
-    if (shift < 0 || shift > 8 || (shift && c->configured && c->cfg.bits + shift > 16)) return fail(RAISR_HIP_EINVAL, "sample shift out of range for the sample size");
+    // stored = sample << shift must fit the plane's sample type (8-bit content lives in bytes: no room; 10-bit in 16 bits: up to 6)
+    if (shift < 0 || shift > 8 || (shift && c->configured && c->cfg.bits + shift > (c->cfg.bits == 8 ? 8 : 16)))
+        return fail(RAISR_HIP_EINVAL, "sample shift out of range for the sample size");
     c->sample_shift = shift;
     return RAISR_HIP_OK;
 }
@@ -1276,7 +1387,8 @@ int raisr_hip_process_y_device_batch(raisr_hip_ctx* c, int n, const void* const*
         si = (const char*)d_in[1] - (const char*)d_in[0]; so = (char*)d_out[1] - (char*)d_out[0];
         for (int i = 2; i < n && one_launch; i++)
             one_launch = ((const char*)d_in[i] - (const char*)d_in[i - 1]) == si && ((char*)d_out[i] - (char*)d_out[i - 1]) == so;
-        one_launch = one_launch && si > 0 && so > 0 && si % bps == 0 && so % bps == 0;
+        // planes of a batch must not overlap: at least one plane apart
+        one_launch = one_launch && si >= (ptrdiff_t)(in_pitch * (size_t)g.in_height) && so >= (ptrdiff_t)(out_pitch * (size_t)g.out_height) && si % bps == 0 && so % bps == 0;
     }
     if (!one_launch) {
         for (int i = 0; i < n; i++) {
@@ -1290,10 +1402,12 @@ int raisr_hip_process_y_device_batch(raisr_hip_ctx* c, int n, const void* const*
         const int blending = c->blending;
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+        // (a device-wide synchronise and a reallocation of every scratch plane: once per context and batch size)
+        const int old_cap = c->batch_cap;
         c->batch_cap = n;
         const int rc = raisr_hip_configure(c, &cfg);
         c->blending = blending;
-        if (rc) return rc;
+        if (rc) { c->batch_cap = old_cap; return rc; }             // the context is unconfigured now (raisr_hip_configure's contract); the cap did not grow
     }
     c->zb_n = n; c->zb_in_stride = (size_t)si / bps; c->zb_out_stride = (size_t)so / bps;
     const int rc = process_y_device_impl(c, d_in[0], in_pitch, d_out[0], out_pitch, stream, 1, NoRowsDone());
@@ -1529,6 +1643,10 @@ int raisr_hip_process_host_async(raisr_hip_ctx* c,
     if (!c || !in_y || !out_y) return fail(RAISR_HIP_EINVAL, "null plane");
     if (!c->configured) return fail(RAISR_HIP_ESTATE, "configure first");
     HIP_TRY(hipSetDevice(c->device));
+    // host planes are LSB-aligned whatever raisr_hip_set_sample_shift said for the device-frame entries (raisr_hip.h; the reference's
+    // CPU path ignores bitShift): the kernels launched from here run with shift 0, the context's setting comes back on every exit
+    struct ShiftOff { raisr_hip_ctx* c; int saved; ~ShiftOff() { c->sample_shift = saved; } } shift_off{c, c->sample_shift};
+    c->sample_shift = 0;
     const raisr_hip_config& g = c->cfg;
     const int bps = g.bits == 8 ? 1 : 2;
     const bool chroma = in_u && out_u && in_v && out_v && cin_w > 0 && cin_h > 0 && cout_w > 0 && cout_h > 0;

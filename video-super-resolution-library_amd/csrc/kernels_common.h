@@ -48,6 +48,18 @@ struct PassParams {
                                  // path pipelines the download of finished rows with the kernels of the next rows)
 };
 
+// Deferred exact path of k_hashfilter_ac<.., DEFER> (kernels_hash_certify.h: hash_phase_defer; kernels_fix.h: k_fix_ac).  The pixels
+// whose bucket the certified hash stage cannot vouch for are filtered with their approximate bucket and listed here, one
+// region per (tile, wave) -- no atomics, no workgroup barrier; k_fix_ac, stream-ordered between the main kernel and k_blend,
+// computes their exact bucket and overwrites the HR value of those whose bucket was wrong.
+constexpr unsigned kWaveCap = 64;   // entries per wave region (of the wave's 256 pixels); a wave with more takes the all-exact code for its rows itself
+struct FixAc {
+    uint8_t* counts;             // [frame][tile][4]: entries in wave w's region, 0xFF = the wave ran the all-exact code (nothing listed)
+    uint16_t* entries;           // [frame][tile][4][kWaveCap]: row within the wave's four (2 bits) | column within the tile (6) | approximate bucket << 8
+    int tiles_x;                 // tiles per tile row of the plane (tile id = tile row * tiles_x + tile column)
+    unsigned zs_tiles;           // frame batches: tiles per frame
+};
+
 #ifdef RAISR_HIP_DEV
 // development builds: wave-cycles per phase of the fused kernel (s_memtime at the phase boundaries of every wave, summed over the launch;
 // the instrumentation itself costs ~10 % -- read the shares, not the totals).  raisr_hip_dev_phase_stats() reads and clears them.

@@ -178,39 +178,17 @@ template <> struct GradOf<uint8_t> { using type = gh2; };
 // AVX2ALL: asm=avx2 frames -- every column takes the RCPPS/RSQRTPS flavour, inlined as straight-line code with both
 // LUTs (8 KB) staged in LDS; otherwise the AVX-512 flavour with the out-of-line AVX2 replay of the tail columns.
 //
-// hash_phase: the work of one tile once its LR window (origin (r0-6, c0-6), row stride LW) is in sL.  Returns, per
+// hash_rows_exact: the all-exact tensor + hash of the wave's R rows of a tile whose gradient tile is in sG.  Returns, per
 // lane (= column c0+lane) and row j of the wave's R rows, hA = first hash (0xFF: pixel not filtered) and hB = the
-// AVX2 re-hash of an overlap column (0xFF elsewhere).  Ends with every wave past its last LDS read of sG.
-template <int R, bool AVX2ALL, int LW, typename GT = f2>
-__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, GT* sG,
-                                           const uint2* sTab, const uint16_t* sLut, int c0, int r0,
-                                           unsigned (&hA)[R], unsigned (&hB)[R], unsigned tid = threadIdx.x)
+// AVX2 re-hash of an overlap column (0xFF elsewhere).  No workgroup barrier inside: a wave can run it on its own
+// (k_hashfilter_ac's wave-level fallback); `sTab` may point at LDS or at global memory (P.tab14).
+template <int R, bool AVX2ALL, typename GT = f2>
+__device__ __forceinline__ void hash_rows_exact(const PassParams& P, const GaussW& gw, const GT* sG,
+                                                const uint2* sTab, const uint16_t* sLut, int c0, int r0,
+                                                unsigned (&hA)[R], unsigned (&hB)[R], unsigned tid = threadIdx.x)
 {
-    constexpr int TH = 4 * R;
-    constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
+    constexpr int GW_ = 74;
     const int lane = tid & 63, w = tid >> 6;
-    // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
-    {
-        auto grad = [&](int ty, int tx) {
-            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
-            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
-            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
-        };
-        const int wu = __builtin_amdgcn_readfirstlane(w);
-        __builtin_assume(wu >= 0 && wu < 4);
-#pragma unroll
-        for (int it = 0; it < (GH + 3) / 4; it++)                                       // columns [0,64): wave = row
-            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
-        constexpr unsigned NR = GH * (GW_ - 64);
-#pragma unroll
-        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {                           // the 10 right-hand columns
-            const unsigned idx = tid + 256u * it;
-            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
-            if (idx < NR) grad(ty, tx);
-        }
-    }
-    __syncthreads();
-
     f2 curAD[R], holdAD[R], t1AD[R];
     float curB[R], holdB[R], t1B[R];
 #pragma unroll
@@ -306,6 +284,40 @@ __device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw
             hA[j] = (inA || inB) ? h : 0xFFu;
         }
     }
+}
+
+// hash_phase: the work of one tile once its LR window (origin (r0-6, c0-6), row stride LW) is in sL: gradient tile,
+// workgroup barrier, hash_rows_exact.
+template <int R, bool AVX2ALL, int LW, typename GT = f2>
+__device__ __forceinline__ void hash_phase(const PassParams& P, const GaussW& gw, const float* sL, GT* sG,
+                                           const uint2* sTab, const uint16_t* sLut, int c0, int r0,
+                                           unsigned (&hA)[R], unsigned (&hB)[R], unsigned tid = threadIdx.x)
+{
+    constexpr int TH = 4 * R;
+    constexpr int GW_ = 74, GH = TH + 10;   // gradient tile incl. 5-px halo
+    const int lane = tid & 63, w = tid >> 6;
+    // G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
+    {
+        auto grad = [&](int ty, int tx) {
+            const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];        // GetGx: row below - row above
+            const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];      // GetGy: right - left
+            grad_store(&sG[ty * GW_ + tx], gxv, gyv);
+        };
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+#pragma unroll
+        for (int it = 0; it < (GH + 3) / 4; it++)                                       // columns [0,64): wave = row
+            if (wu + 4 * it < GH) grad(wu + 4 * it, lane);
+        constexpr unsigned NR = GH * (GW_ - 64);
+#pragma unroll
+        for (unsigned it = 0; it < (NR + 255u) / 256u; it++) {                           // the 10 right-hand columns
+            const unsigned idx = tid + 256u * it;
+            const int ty = (int)(idx / (GW_ - 64)), tx = 64 + (int)(idx - (unsigned)ty * (GW_ - 64));
+            if (idx < NR) grad(ty, tx);
+        }
+    }
+    __syncthreads();
+    hash_rows_exact<R, AVX2ALL, GT>(P, gw, sG, sTab, sLut, c0, r0, hA, hB, tid);
 }
 
 // stage the approximation tables of the hash flavour into LDS

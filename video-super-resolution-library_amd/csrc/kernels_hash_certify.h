@@ -348,6 +348,83 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     RAISR_PHASE(5);                                        // worklist: table staging, exact tensors, exact hashes, three barriers
 }
 
+// hash_phase_defer: the hash stage of k_hashfilter_ac<.., DEFER> (the production kernel).  As hash_phase_ac up to the certification;
+// then every wave is on its own: the pixels it could not certify keep their approximate bucket for the filter stage and go, with
+// that bucket, into the wave's region of the frame's fix list (FixAc; k_fix_ac repairs those whose exact bucket differs before
+// k_blend reads the HR plane).  A wave with more than kWaveCap of them (synthetic content: 1-px patterns, exact symmetries) runs
+// the all-exact code for its four rows instead (hash_rows_exact on the gradient tile, tables from global memory) and lists nothing.
+// Against the in-tile worklist of hash_phase_ac: no LDS atomics, no list, no table staging, three workgroup barriers fewer, and
+// the 16-lane exact tensors + one-lane hashes of the 1-3 % uncertified pixels leave the issue-bound main kernel for a small
+// latency-bound one that overlaps the main kernels of the other frames in flight.  The gradient tile sG stays intact to the end
+// of the stage (the symmetric filter stage's zero block lives in the wave's own sV rows instead).
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m)      // number of set bits of m below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <int LW, typename GT>
+__device__ __forceinline__ void hash_phase_defer(const PassParams& P, const GaussW& gw, const SepW& S, const GT* sG, typename FVec<4>::type* sV,
+                                                 uint8_t* sH, uint8_t* sH2, const FixAc& F, unsigned region, int c0, int r0, unsigned tid = threadIdx.x)
+{
+    constexpr int TW = 64, RPW = 4;
+    const int lane = tid & 63, w = tid >> 6;
+    float ta[RPW], tb[RPW], td[RPW];
+    RAISR_PHASE_DECL;
+    tensor_acN<RPW, GT>(S, sG, sV, ta, tb, td, tid);
+    RAISR_PHASE(2);                                        // V pass + barrier + H pass
+    const int c = c0 + lane;
+    const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+    const int fl = inB ? 1 : 0;
+    const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
+    unsigned long long ub[RPW];
+    unsigned bk[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+        const int prow = RPW * w + j;
+        const int r = r0 + prow;
+        const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
+        unsigned bucket;
+        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket);
+        const bool zero = (ta[j] + td[j]) == 0.0f;          // flat window: the reference's tensor is exactly (0, 0, 0) as well
+        cert |= zero;
+        const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
+        const unsigned bB = zero ? (unsigned)P.zero_bucket[1] : bucket;
+        sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
+        sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
+        ub[j] = __ballot(zone && !cert);
+        bk[j] = bucket;
+    }
+    RAISR_PHASE(3);                                        // approximate hash + certification
+    unsigned n = 0;
+#pragma unroll
+    for (int j = 0; j < RPW; j++) n += (unsigned)__builtin_popcountll(ub[j]);
+    n = __builtin_amdgcn_readfirstlane(n);
+    unsigned count = n;
+    if (n > kWaveCap) {                                    // wave-uniform
+        unsigned hA[RPW], hB[RPW];
+        hash_rows_exact<RPW, false, GT>(P, gw, sG, P.tab14, nullptr, c0, r0, hA, hB, tid);
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            sH[(RPW * w + j) * TW + lane] = (uint8_t)hA[j];
+            sH2[(RPW * w + j) * TW + lane] = (uint8_t)hB[j];
+        }
+        count = 0xFFu;
+    } else if (n) {
+        uint16_t* list = F.entries + (size_t)region * kWaveCap;
+        unsigned base = 0;
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            if ((ub[j] >> lane) & 1ull) list[base + lane_rank(ub[j])] = (uint16_t)((unsigned)j | ((unsigned)lane << 2) | (bk[j] << 8));
+            base += (unsigned)__builtin_popcountll(ub[j]);
+        }
+    }
+    if (lane == 0) {
+        F.counts[region] = (uint8_t)count;
+        if (P.cert_stats && n) atomicAdd(&P.cert_stats[0], n);
+    }
+    RAISR_PHASE(5);                                        // listing / the wave-level all-exact fallback
+}
+
 // Test hook: the certified hash stage's decision for arbitrary APPROXIMATE tensor triples (a', b', d'): bucket and whether
 // it would be certified, by the very approx_hash the kernels run (flavour 0: AVX-512 table error, 1: AVX2).
 __global__ __launch_bounds__(256) void k_debug_approx_hash(const float* __restrict__ abd, unsigned n, PassParams P, SepW S, int fl,

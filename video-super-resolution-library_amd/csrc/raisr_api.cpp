@@ -58,6 +58,7 @@ struct State {
     raisr_hip_stream *ring = nullptr;
     unsigned asyncDepth = 0;                      // RNLHandler_SetAsyncDepth; 0 = no ring
     bool deviceChosen = false;                    // RNLSetOpenCLContext named a device; otherwise RAISR_HIP_DEVICE / 0
+    std::vector<int> devices;                     // RNLSetDeviceList: GPUs of the asynchronous ring (empty: RAISR_HIP_DEVICES, else the one device)
     bool external = false;                        // asm = HIPExternal: plane pointers are device pointers
     void *externalStream = nullptr;               // caller's hipStream_t for external frames (NULL: own stream + wait)
 } G;
@@ -567,9 +568,11 @@ RNLERRORTYPE RNLProcess(VideoDataType *inY, VideoDataType *inCr, VideoDataType *
         // NV12 / P010 surfaces: both chroma descriptors flag one interleaved plane (RaisrDefaults.h) -- all four or none
         const unsigned il = (inCr->bitShift & inCb->bitShift & outCr->bitShift & outCb->bitShift) & RAISR_HIP_INTERLEAVED2;
         if (((inCr->bitShift | inCb->bitShift | outCr->bitShift | outCb->bitShift) & RAISR_HIP_INTERLEAVED2) && !il) return RNLErrorBadParameter;
-        // bitShift (low bits): samples of the surface are MSB-aligned by that many bits (P010: 6), the same on every plane
+        // bitShift (low bits): samples of the surface are MSB-aligned by that many bits (P010: 6).  Read from the INPUT descriptors
+        // only, as the reference does (Raisr.cpp:1313-1348: inY / inCr / inCb->bitShift); a caller that leaves the output
+        // descriptors' field at 0 gets the input's alignment on the output, as there.
         const unsigned sh = inY->bitShift & 0xFFu;
-        for (const VideoDataType *p : {inCr, inCb, outY, outCr, outCb}) if ((p->bitShift & 0xFFu) != sh) return RNLErrorBadParameter;
+        for (const VideoDataType *p : {inCr, inCb}) if ((p->bitShift & 0xFFu) != sh) return RNLErrorBadParameter;
         if (raisr_hip_set_sample_shift(G.ctx, (int)sh) != RAISR_HIP_OK) return RNLErrorBadParameter;
         int rc = raisr_hip_process_frame_device_ex(G.ctx, inY->pData, inY->step, outY->pData, outY->step,
                                                    inCr->pData, inCb->pData, inCr->step, outCr->pData, outCb->pData, outCr->step,
@@ -644,6 +647,7 @@ RNLERRORTYPE RNLDeinit()
     G.deviceChosen = false;
     G.device = 0;
     G.asyncDepth = 0;
+    G.devices.clear();
     gPins.clear();
     return RNLErrorNone;
 }
@@ -667,6 +671,18 @@ RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth)
     if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) return RNLErrorBadParameter;      // collect first
     dropRing();
     G.asyncDepth = depth;
+    return RNLErrorNone;
+}
+
+RNLERRORTYPE RNLSetDeviceList(const char *devices)
+{
+    if (!devices) return RNLErrorBadParameter;
+    if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) return RNLErrorBadParameter;      // collect first
+    int list[RAISR_HIP_STREAM_MAX_DEVICES];
+    const int n = raisr_hip_parse_device_list(devices, list, RAISR_HIP_STREAM_MAX_DEVICES);
+    if (n < 0) return RNLErrorBadParameter;
+    dropRing();
+    G.devices.assign(list, list + n);
     return RNLErrorNone;
 }
 
@@ -698,7 +714,18 @@ RNLERRORTYPE RNLSubmit(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
         return RNLErrorUndefined;
     };
     if (!G.ring) {
-        int rc = raisr_hip_stream_create(&G.ring, G.device, (int)G.asyncDepth);
+        // the ring's GPUs: RNLSetDeviceList, else RAISR_HIP_DEVICES, else the handler's one device
+        std::vector<int> devs = G.devices;
+        if (devs.empty()) {
+            if (const char *e = std::getenv("RAISR_HIP_DEVICES")) {
+                int list[RAISR_HIP_STREAM_MAX_DEVICES];
+                const int n = raisr_hip_parse_device_list(e, list, RAISR_HIP_STREAM_MAX_DEVICES);
+                if (n < 0) { std::cout << "[RAISR ERROR] RAISR_HIP_DEVICES=" << e << ": not a list of HIP devices of this machine" << std::endl; return RNLErrorBadParameter; }
+                devs.assign(list, list + n);
+            }
+        }
+        if (devs.empty()) devs.push_back(G.device);
+        int rc = raisr_hip_stream_create_multi(&G.ring, devs.data(), (int)devs.size(), (int)G.asyncDepth);
         if (rc != RAISR_HIP_OK) { G.ring = nullptr; return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : failed("async ring"); }
         for (unsigned p = 0; p < G.passes && rc == RAISR_HIP_OK; p++) {
             const PassModel &M = G.model[p];
@@ -764,6 +791,7 @@ RNLERRORTYPE RNLHandler_Deinit(void)
 }
 
 RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth) { return RNLSetAsyncDepth(depth); }
+RNLERRORTYPE RNLHandler_SetDeviceList(const char *devices) { return RNLSetDeviceList(devices); }
 
 RNLERRORTYPE RNLHandler_Submit(VideoDataType *inY, VideoDataType *inU, VideoDataType *inV,
                                VideoDataType *outY, VideoDataType *outU, VideoDataType *outV, BlendingMode blendingMode)

@@ -16,63 +16,114 @@
 #include "../../include/raisr_hip.h"
 
 struct raisr_hip_stream {
-    int device = 0;
+    std::vector<int> devices;        // one entry per device slot (a device may appear twice); lane L runs on devices[L % devices.size()]
     std::vector<raisr_hip_ctx*> lanes;
     std::vector<char> busy;          // lane has a submitted, not yet collected frame
     size_t head = 0, tail = 0;       // next lane to submit to / to collect from
     bool configured = false;
-    // One stream per lane, at most kMaxLanes = 4 of them (the runtime has four hardware queues; more streams alias onto shared
-    // queues): a lane runs whole frames -- uploads, Y kernels, the two cheap chroma upscales, one download -- on its stream.
+    // One stream per lane, at most RAISR_HIP_STREAM_MAX_DEPTH = 4 per device (the runtime has four hardware queues per device;
+    // more streams alias onto shared queues): a lane runs whole frames -- uploads, Y kernels, the two cheap chroma upscales, one
+    // download -- on its stream.
     // Measured on the way here (scripts/stream_probe.py, stream_trace.sh, copy_engine_probe.hip; 1080p -> 4K yuv420p, PCIe
     // ceiling of the box 4.19 k fps): this layout 3.9-4.2 k fps in 18 of 18 runs; two streams per lane (chroma on its own,
     // round 2a) anywhere between 2.6 k and 4.0 k; six lanes on four streams 2.7 k; uploads on a shared upload stream make the
     // runtime hand the downloads to a copy KERNEL instead of the DMA engine (takes CUs from the next frame's kernels): 2.0-3.0 k.
-    hipStream_t comp[4] = {nullptr, nullptr, nullptr, nullptr};
-    int nstreams = 0;
+    std::vector<hipStream_t> comp;   // comp[L]: lane L's stream (on the lane's device), empty with RAISR_HIP_RING_LANE_STREAMS=1
+    int device_of_lane(size_t lane) const { return devices[lane % devices.size()]; }
 };
 
 static void destroy_streams(raisr_hip_stream* s)
 {
-    (void)hipSetDevice(s->device);
-    for (hipStream_t& c : s->comp) if (c) (void)hipStreamDestroy(c);
+    for (size_t i = 0; i < s->comp.size(); i++)
+        if (s->comp[i]) { (void)hipSetDevice(s->device_of_lane(i)); (void)hipStreamDestroy(s->comp[i]); }
+    s->comp.clear();
 }
 
 extern "C" {
 
-int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
+// Frame i -> lane i % (n * depth); lanes are laid out device-interleaved (lane L on devices[L % n]), so frame i runs on
+// devices[i % n] and consecutive frames of one device use its `depth` lanes in turn.
+int raisr_hip_stream_create_multi(raisr_hip_stream** out, const int* devices, int n, int depth)
 {
-    if (!out || depth < 1 || depth > RAISR_HIP_STREAM_MAX_DEPTH) return RAISR_HIP_EINVAL;   // more lanes than that were never faster (see raisr_hip_stream::comp): refused, not clamped
+    if (!out || !devices || n < 1 || n > RAISR_HIP_STREAM_MAX_DEVICES || depth < 1 || depth > RAISR_HIP_STREAM_MAX_DEPTH) return RAISR_HIP_EINVAL;   // more lanes per device were never faster: refused, not clamped
     raisr_hip_stream* s = new raisr_hip_stream();
-    s->device = device_index;
-    for (int i = 0; i < depth; i++) {
+    s->devices.assign(devices, devices + n);
+    const size_t nl = (size_t)n * (size_t)depth;
+    auto drop = [&](int rc) {
+        for (raisr_hip_ctx* p : s->lanes) { (void)raisr_hip_use_streams(p, nullptr, nullptr, nullptr); raisr_hip_destroy(p); }
+        destroy_streams(s);
+        delete s;
+        return rc;
+    };
+    for (size_t i = 0; i < nl; i++) {
         raisr_hip_ctx* c = nullptr;
-        const int rc = raisr_hip_create(&c, device_index);
-        if (rc != RAISR_HIP_OK) {
-            for (raisr_hip_ctx* p : s->lanes) raisr_hip_destroy(p);
-            delete s;
-            return rc;
-        }
+        const int rc = raisr_hip_create(&c, s->device_of_lane(i));
+        if (rc != RAISR_HIP_OK) return drop(rc);
         s->lanes.push_back(c);
     }
-    s->busy.assign((size_t)depth, 0);
+    s->busy.assign(nl, 0);
     const char* legacy = getenv("RAISR_HIP_RING_LANE_STREAMS");         // A/B switch: 1 = every lane on its own streams (round-2a behaviour)
     if (!(legacy && atoi(legacy) != 0)) {
-        s->nstreams = depth;
-        bool ok = hipSetDevice(device_index) == hipSuccess;
-        for (int i = 0; ok && i < s->nstreams; i++) ok = hipStreamCreateWithFlags(&s->comp[i], hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < depth; i++) {
-            hipStream_t c = s->comp[i % s->nstreams];
-            ok = raisr_hip_use_streams(s->lanes[(size_t)i], c, c, c) == RAISR_HIP_OK;
-        }
-        if (!ok) {
-            for (raisr_hip_ctx* p : s->lanes) raisr_hip_destroy(p);
-            destroy_streams(s);
-            delete s;
-            return RAISR_HIP_ERUNTIME;
-        }
+        s->comp.assign(nl, nullptr);
+        bool ok = true;
+        for (size_t i = 0; ok && i < nl; i++)
+            ok = hipSetDevice(s->device_of_lane(i)) == hipSuccess && hipStreamCreateWithFlags(&s->comp[i], hipStreamNonBlocking) == hipSuccess &&
+                 raisr_hip_use_streams(s->lanes[i], s->comp[i], s->comp[i], s->comp[i]) == RAISR_HIP_OK;
+        if (!ok) return drop(RAISR_HIP_ERUNTIME);
     }
     *out = s;
     return RAISR_HIP_OK;
+}
+
+int raisr_hip_stream_create(raisr_hip_stream** out, int device_index, int depth)
+{
+    return raisr_hip_stream_create_multi(out, &device_index, 1, depth);
+}
+
+int raisr_hip_stream_device_count(const raisr_hip_stream* s) { return s ? (int)s->devices.size() : 0; }
+
+int raisr_hip_stream_device_of_frame(const raisr_hip_stream* s, unsigned long long frame_index)
+{
+    return (s && !s->devices.empty()) ? s->devices[(size_t)(frame_index % s->devices.size())] : -1;
+}
+
+int raisr_hip_parse_device_list(const char* text, int* devices, int max)
+{
+    return raisr_hip_parse_device_list_n(text, raisr_hip_device_count(), devices, max);
+}
+
+// frame -> (device slot, lane on that device) of an n-device ring with `depth` lanes per device: the map submit() and collect() walk
+void raisr_hip_ring_slot(int n_devices, int depth, unsigned long long frame_index, int* device_slot, int* lane_on_device)
+{
+    if (n_devices < 1) n_devices = 1;
+    if (depth < 1) depth = 1;
+    const unsigned long long lane = frame_index % ((unsigned long long)n_devices * (unsigned long long)depth);
+    if (device_slot) *device_slot = (int)(lane % (unsigned long long)n_devices);
+    if (lane_on_device) *lane_on_device = (int)(lane / (unsigned long long)n_devices);
+}
+
+int raisr_hip_parse_device_list_n(const char* text, int have, int* devices, int max)
+{
+    if (!text || !devices || max < 1) return -1;
+    while (*text == ' ') text++;
+    if (!*text) return 0;
+    if (!strcmp(text, "all")) {
+        int n = 0;
+        for (int d = 0; d < have && n < max; d++) devices[n++] = d;
+        return n > 0 ? n : -1;
+    }
+    int n = 0;
+    const char* p = text;
+    while (*p) {
+        char* end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || v >= have || n >= max) return -1;
+        devices[n++] = (int)v;
+        p = end;
+        while (*p == ' ') p++;
+        if (*p == ',') { p++; if (!*p) return -1; } else if (*p) return -1;
+    }
+    return n;
 }
 
 void raisr_hip_stream_destroy(raisr_hip_stream* s)
@@ -91,11 +142,31 @@ int raisr_hip_stream_set_model(raisr_hip_stream* s, int pass_index, const float*
     if (!s) return RAISR_HIP_EINVAL;
     for (size_t i = 0; i < s->lanes.size(); i++)
         if (s->busy[i]) return RAISR_HIP_ESTATE;                   // a lane's kernels may still be reading its bank
-    for (raisr_hip_ctx* c : s->lanes) {
-        const int rc = raisr_hip_set_model(c, pass_index, bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
-        if (rc != RAISR_HIP_OK) return rc;
+    const size_t nd = s->devices.size();
+    if (nd == 1) {
+        for (raisr_hip_ctx* c : s->lanes) {
+            const int rc = raisr_hip_set_model(c, pass_index, bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
+            if (rc != RAISR_HIP_OK) return rc;
+        }
+        return RAISR_HIP_OK;
     }
-    return RAISR_HIP_OK;
+    // several devices: the model is packed once, crosses PCIe once (to devices[0]) and reaches the other devices by the
+    // in-process broadcast (RCCL over xGMI); every lane then takes a device-local copy
+    const size_t bytes = raisr_hip_model_blob_bytes(hashkeys, pixel_types);
+    if (!bytes) return RAISR_HIP_EINVAL;
+    std::vector<unsigned char> host(bytes);
+    int rc = raisr_hip_pack_model_blob(host.data(), bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
+    if (rc != RAISR_HIP_OK) return rc;
+    std::vector<void*> blobs(nd, nullptr);
+    auto release = [&]() { for (size_t d = 0; d < nd; d++) if (blobs[d]) { (void)hipSetDevice(s->devices[d]); (void)hipFree(blobs[d]); } };
+    for (size_t d = 0; d < nd && rc == RAISR_HIP_OK; d++)
+        if (hipSetDevice(s->devices[d]) != hipSuccess || hipMalloc(&blobs[d], bytes) != hipSuccess) { blobs[d] = nullptr; rc = RAISR_HIP_ENOMEM; }
+    if (rc == RAISR_HIP_OK && (hipSetDevice(s->devices[0]) != hipSuccess || hipMemcpy(blobs[0], host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = RAISR_HIP_ERUNTIME;
+    if (rc == RAISR_HIP_OK) rc = raisr_hip_broadcast_model_blob_devices(s->devices.data(), (int)nd, blobs.data(), bytes);
+    for (size_t i = 0; i < s->lanes.size() && rc == RAISR_HIP_OK; i++)
+        rc = raisr_hip_set_model_blob_device(s->lanes[i], pass_index, blobs[i % nd], bytes, nullptr);
+    release();
+    return rc;
 }
 
 // Multi-GPU streams (BASELINE C5): the rank received the packed blob by raisr_hip_broadcast_model_blob; every lane copies it.
@@ -197,13 +268,13 @@ int raisr_hip_stream_quiesce(raisr_hip_stream* s)
 void* raisr_hip_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;        // portable: every device of a multi-device ring copies from / to it
     return p;
 }
 void raisr_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int raisr_hip_host_register(void* p, size_t bytes)
 {
-    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);          // portable: every device of a multi-device ring
     if (e == hipSuccess) return RAISR_HIP_OK;
     (void)hipGetLastError();                                                     // a refused registration is not a sticky error
     return e == hipErrorHostMemoryAlreadyRegistered ? RAISR_HIP_ESTATE : RAISR_HIP_ERUNTIME;

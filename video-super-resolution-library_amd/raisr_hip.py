@@ -109,6 +109,15 @@ def lib():
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_stream_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.raisr_hip_stream_device_count.argtypes = [ctypes.c_void_p]
+        L.raisr_hip_stream_device_of_frame.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+        L.raisr_hip_parse_device_list.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_parse_device_list_n.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.raisr_hip_ring_slot.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+        L.raisr_hip_ring_slot.restype = None
+        L.raisr_hip_broadcast_model_blob_devices.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+        L.RNLHandler_SetDeviceList.argtypes = [ctypes.c_char_p]
         L.raisr_hip_stream_destroy.argtypes = [ctypes.c_void_p]
         L.raisr_hip_stream_destroy.restype = None
         L.raisr_hip_stream_depth.argtypes = [ctypes.c_void_p]
@@ -204,6 +213,26 @@ def RNLHandler_Deinit():
 
 def RNLHandler_SetAsyncDepth(depth):
     return int(lib().RNLHandler_SetAsyncDepth(ctypes.c_uint(depth)))
+
+
+def RNLHandler_SetDeviceList(devices):
+    """GPUs of the asynchronous ring: "0,1,2" | "all" | "" (RaisrHandler.h)."""
+    return lib().RNLHandler_SetDeviceList(devices.encode() if isinstance(devices, str) else devices)
+
+
+def parse_device_list(text, devices_present=None):
+    """-> list of device ordinals, or None for a malformed list (raisr_hip_parse_device_list[_n])."""
+    buf = (ctypes.c_int * 16)()
+    t = text.encode()
+    n = lib().raisr_hip_parse_device_list(t, buf, 16) if devices_present is None else lib().raisr_hip_parse_device_list_n(t, devices_present, buf, 16)
+    return None if n < 0 else [int(buf[i]) for i in range(n)]
+
+
+def ring_slot(n_devices, depth, frame_index):
+    """(device slot, lane on that device) of frame `frame_index` in an n-device ring (raisr_hip_ring_slot)."""
+    d, l = ctypes.c_int(), ctypes.c_int()
+    lib().raisr_hip_ring_slot(n_devices, depth, frame_index, ctypes.byref(d), ctypes.byref(l))
+    return d.value, l.value
 
 
 def RNLHandler_Submit(in_planes, out_planes, blending=CountOfBitsChanged):
@@ -521,15 +550,20 @@ class PinnedFrame:
 
 
 class RaisrStream:
-    """depth frames in flight through one GPU: submit() enqueues, collect() waits for the oldest frame."""
+    """depth frames in flight per GPU: submit() enqueues, collect() waits for the oldest frame.  `device`: one ordinal, or a list
+    of ordinals (raisr_hip_stream_create_multi: frame i runs on device[i % n], one host thread drives them all)."""
 
     def __init__(self, device, folder, in_w, in_h, out_w, out_h, bits=8, full_range=False, passes=1, mode=1,
                  hash_variant=HASH_AVX512, blending=BLEND_COUNT, chroma=None, depth=4, tie=TIE_HALF_UP, blobs=None):
         """`blobs`: per-pass (device pointer, bytes) of packed model blobs already in device memory (the multi-GPU start-up:
         rank 0 packs, RCCL broadcasts); otherwise the model is read from `folder`."""
         self._h = ctypes.c_void_p()
-        _check(lib().raisr_hip_stream_create(ctypes.byref(self._h), device, depth), "raisr_hip_stream_create")
-        self.depth = int(lib().raisr_hip_stream_depth(self._h))      # the library builds at most 4 lanes
+        if isinstance(device, (list, tuple)):
+            arr = (ctypes.c_int * len(device))(*device)
+            _check(lib().raisr_hip_stream_create_multi(ctypes.byref(self._h), arr, len(device), depth), "raisr_hip_stream_create_multi")
+        else:
+            _check(lib().raisr_hip_stream_create(ctypes.byref(self._h), device, depth), "raisr_hip_stream_create")
+        self.depth = int(lib().raisr_hip_stream_depth(self._h))      # frames in flight: (at most 4) lanes per device x devices
         try:
             for p in range(passes):
                 if blobs is not None:
