@@ -127,11 +127,14 @@ def test_plugin_api_ring_over_a_device_list(how, monkeypatch):
             assert np.array_equal(outs[done][0], refs[done]), done
             done += 1; inflight -= 1
         assert done == n
-        assert R.RNLHandler_SetDeviceList("") == 0                                                # back to the single device
-        assert R.RNLHandler_Submit((ys[0], us[0], us[0]), outs[0]) == 0
-        assert R.RNLHandler_Submit((ys[1], us[1], us[1]), outs[1]) == 0
-        assert R.RNLHandler_Submit((ys[2], us[2], us[2]), outs[2]) == R.RNLErrorInsufficientResources
-        assert R.RNLHandler_Collect() == 0 and R.RNLHandler_Collect() == 0
+        assert R.RNLHandler_SetDeviceList("") == 0                                                # no list: RAISR_HIP_DEVICES if set, else the single device
+        cap = 4 if how == "env" else 2
+        for k in range(cap):
+            assert R.RNLHandler_Submit((ys[k], us[k], us[k]), outs[k]) == 0
+        assert R.RNLHandler_Submit((ys[cap], us[cap], us[cap]), outs[cap]) == R.RNLErrorInsufficientResources
+        for k in range(cap):
+            assert R.RNLHandler_Collect() == 0
+            assert np.array_equal(outs[k][0], refs[k]), k
     finally:
         assert R.RNLHandler_Deinit() == 0
 

@@ -427,7 +427,7 @@ void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void*
         timer_end(c, s, slot);
         const unsigned tile_first = (unsigned)P.tile_y0 * plane_tiles.x, tile_count = grid.x * grid.y;
         timer_begin(c, "k_fix_ac", s, slot);
-        hipLaunchKernelGGL((k_fix_ac<TOut>), dim3((tile_count + 3u) / 4u, 1, grid.z), dim3(256), 0, s, (const TOut*)lrp, P, F, c->d_hash[pass], c->d_hr[pass], tile_first, tile_count);
+        hipLaunchKernelGGL((k_fix_ac<TOut>), dim3((tile_count + 4u * kFixTiles - 1u) / (4u * kFixTiles), 1, grid.z), dim3(256), 0, s, (const TOut*)lrp, P, F, c->d_hash[pass], c->d_hr[pass], tile_first, tile_count);
         timer_end(c, s, slot);
         return;
     }

@@ -109,15 +109,16 @@ def lib():
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
         L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
-        L.raisr_hip_stream_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        L.raisr_hip_stream_device_count.argtypes = [ctypes.c_void_p]
-        L.raisr_hip_stream_device_of_frame.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
-        L.raisr_hip_parse_device_list.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
-        L.raisr_hip_parse_device_list_n.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-        L.raisr_hip_ring_slot.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
-        L.raisr_hip_ring_slot.restype = None
-        L.raisr_hip_broadcast_model_blob_devices.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
-        L.RNLHandler_SetDeviceList.argtypes = [ctypes.c_char_p]
+        if os.environ.get("RAISR_HIP_LIB") is None or hasattr(L, "raisr_hip_stream_create_multi"):     # (an older A/B build may lack the multi-device ring)
+            L.raisr_hip_stream_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            L.raisr_hip_stream_device_count.argtypes = [ctypes.c_void_p]
+            L.raisr_hip_stream_device_of_frame.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+            L.raisr_hip_parse_device_list.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
+            L.raisr_hip_parse_device_list_n.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+            L.raisr_hip_ring_slot.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+            L.raisr_hip_ring_slot.restype = None
+            L.raisr_hip_broadcast_model_blob_devices.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+            L.RNLHandler_SetDeviceList.argtypes = [ctypes.c_char_p]
         L.raisr_hip_stream_destroy.argtypes = [ctypes.c_void_p]
         L.raisr_hip_stream_destroy.restype = None
         L.raisr_hip_stream_depth.argtypes = [ctypes.c_void_p]
