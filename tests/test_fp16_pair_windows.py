@@ -51,3 +51,33 @@ def test_builder_covers_exactly_the_window():
     assert written_b == {(y, x) for y in range(25) for x in range(6, 74)}
     # the centre pixel of the accept test is read as the low half of A[prow + 5][pc + 5]
     assert all((prow + 5, pc + 5) in written_a for prow in range(TH) for pc in range(TW))
+
+
+def _pair_read_extra_cycles(row_stride, b_offset):
+    """LDS cycles lost to bank conflicts by the four pair reads of one filter step (ds_read_b32: two 32-lane groups, bank = dword
+    index mod 32, identical addresses broadcast -- MI355X_MICROARCH.md, LDS): lane (g, l) of chunk ch reads dword
+    array + (k0 / 11) * stride + k0 % 11 + g, k0 = 32 ch + l, array = A (0) for patch columns 0..5, B (b_offset) for 6..10."""
+    extra = 0
+    for ch in range(4):
+        for half in range(2):
+            by_bank = {}
+            for g in (2 * half, 2 * half + 1):
+                for l in range(16):
+                    i, j = divmod(32 * ch + l, 11)
+                    d = (0 if j + 5 < 11 else b_offset) + i * row_stride + j + g
+                    by_bank.setdefault(d % 32, set()).add(d)
+            extra += max(len(v) for v in by_bank.values()) - 1
+    return extra
+
+
+def test_pair_arrays_are_placed_conflict_free():
+    """k_hashfilter16 places array B 15 dwords after array A (kPairPad): no lane pair of a 32-lane half hits one bank with two
+    addresses.  Back to back (round 4) three of the four chunks were 2-way conflicted."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-super-resolution-library_amd", "csrc",
+                            "kernels_fp16.h")).read()
+    pad = int(re.search(r"constexpr int kPairPad = (\d+) \* 4;", src).group(1))
+    assert _pair_read_extra_cycles(LW, 26 * LW + pad) == 0
+    assert _pair_read_extra_cycles(LW, 26 * LW) == 6                # the round-4 layout: 6 extra cycles on 8
+    assert (2 * 26 * LW + pad) * 4 <= (16 + 9) * 74 * 8 + 2048 * 2  # both arrays inside the hash stage's region

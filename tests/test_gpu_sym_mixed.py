@@ -1,11 +1,12 @@
-"""-m gpu: the symmetric filter stage on banks with non-palindromic rows (csrc/kernels_filter.h, filter_phase<.., SYM>, MIXED loop).
+"""-m gpu: the symmetric filter stage on banks with non-palindromic rows (csrc/kernels_filter.h, filter_phase<.., SYM>).
 
-A pixel step that contains a pixel of a non-palindromic bank row fetches the partner block of the lane-major bank; the shipped
-highres banks exercise that with 2 (8-bit) and 50 (10-bit) of 864 rows only.  Here the 8-bit highres bank gets 1 .. 400 of its
-rows perturbed (one tap moved by an ulp, or a row replaced by noise), so that steps with 0, 1 and 4 such pixels, tail re-hash
-columns (width 134) and Randomness blending all meet the partner-block path -- compared bit for bit with the CPU oracle on the
-same bank, and with the eight-load stage (RAISR_HIP_SYM=0).  Above a fifth of the rows the library keeps the eight-load stage
-by itself (400 rows): same comparison, other code path.  (Raisr_AVX512.cpp:134-149, Raisr.cpp:1147-1200.)"""
+The stage redoes the pixels of non-palindromic bank rows with all eight coefficient loads (ballot + plain_step); the shipped
+highres banks exercise that with 2 (8-bit) of 864 rows only.  Here the highres bank gets 1 .. 400 of its rows perturbed (one tap
+moved by an ulp, or a row replaced by noise), so that steps with 0, 1 and 4 such pixels, tail re-hash columns (width 134) and
+Randomness blending all meet the redo path -- compared bit for bit with the CPU oracle on the same bank, and with the eight-load
+stage (RAISR_HIP_SYM=0).  Above 16 such rows (RAISR_HIP_SYM_MAX_ROWS) the library keeps the eight-load stage by itself: same
+comparison, other code path; RAISR_HIP_SYM_MAX_ROWS=1000 forces the redo path on those banks too.
+(Raisr_AVX512.cpp:134-149, Raisr.cpp:1147-1200.)"""
 import os
 
 import numpy as np
@@ -72,7 +73,7 @@ def _gpu(y, bank, qstr, qcoh, qa, bits, asm, blending, preset, env=None):
 
 @pytest.mark.parametrize("nasym", [1, 5, 16, 60, 170, 400])
 @pytest.mark.parametrize("bits", [8, 10])
-def test_partner_block_rows_bit_exact(nasym, bits):
+def test_non_palindromic_rows_bit_exact(nasym, bits):
     import oracle_py as O
     import raisr_hip as R
     import synth
@@ -87,10 +88,12 @@ def test_partner_block_rows_bit_exact(nasym, bits):
                 assert np.array_equal(ref, got), (nasym, bits, w, h, name, blending, int((ref != got).sum()))
                 plain = _gpu(y, bank, qstr, qcoh, qa, bits, R.HASH_AVX512, blending, preset, env={"RAISR_HIP_SYM": "0"})
                 assert np.array_equal(plain, got), (nasym, bits, w, h, name, blending, "eight-load stage differs")
+                forced = _gpu(y, bank, qstr, qcoh, qa, bits, R.HASH_AVX512, blending, preset, env={"RAISR_HIP_SYM_MAX_ROWS": "1000"})
+                assert np.array_equal(forced, got), (nasym, bits, w, h, name, blending, "symmetric stage with redo differs")
 
 
-def test_partner_block_on_a_larger_frame_with_every_step_pattern():
-    """640 x 360 -> 1280 x 720 random frame, 60 perturbed rows: thousands of steps with 1, 2, 3 and 4 partner-block pixels."""
+def test_redo_path_on_a_larger_frame_with_every_step_pattern():
+    """640 x 360 -> 1280 x 720 random frame, 60 perturbed rows, symmetric stage forced: thousands of steps with 1, 2, 3 and 4 redone pixels."""
     import oracle_py as O
     import raisr_hip as R
     import synth
@@ -98,5 +101,5 @@ def test_partner_block_on_a_larger_frame_with_every_step_pattern():
     y = synth.random_y(640, 360, 8, seed=99)
     preset = np.zeros((720, 1280), np.uint8)
     ref = _oracle(y, bank, 8, 2, O.BLEND_COUNT, preset)
-    got = _gpu(y, bank, qstr, qcoh, qa, 8, R.HASH_AVX512, O.BLEND_COUNT, preset)
+    got = _gpu(y, bank, qstr, qcoh, qa, 8, R.HASH_AVX512, O.BLEND_COUNT, preset, env={"RAISR_HIP_SYM_MAX_ROWS": "1000"})
     assert np.array_equal(ref, got), int((ref != got).sum())

@@ -38,36 +38,20 @@ def reference_lanes(p, f):
     return acc, tree(acc)
 
 
-def lane_major_row(f):
-    """k_lane_major_bank's index arithmetic for one 128-float bank row -> the 192-float row the filter stage reads."""
-    out = np.zeros(192, f32)
-    for k in range(192):
-        if k < 128:
-            l, ch = (k & 63) >> 2, (k >> 6) * 4 + (k & 3)
-            tap = 16 * ch + l
-        else:
-            l, i = (k - 128) >> 2, k & 3
-            l2 = (8 - l) & 15
-            tap = 16 * (4 + i) + l2 if l <= 8 else (48 + l if i == 0 else 16 * (3 + i) + l2)
-        out[k] = f[tap]
-    return out
-
-
-def symmetric_lanes(p, f, partner_block=False):
-    lm = lane_major_row(f)
-    cf = [[lm[4 * l + c] for c in range(4)] for l in range(16)]           # the lane's 16-byte load
-    pb = [[lm[128 + 4 * l + c] for c in range(4)] for l in range(16)]     # the partner block (fetched only for steps that need it)
+def symmetric_lanes(p, f):
+    cf = [[f[16 * c + l] for c in range(4)] for l in range(16)]          # the only coefficients a lane loads
     a = [f32(p[l] * cf[l][0]) for l in range(16)]
     for c in range(1, 4):
         a = [fma(p[16 * c + l], cf[l][c], a[l]) for l in range(16)]
     a = [a[(8 - q) % 16] for q in range(16)]                               # partner_xchg
     for q in range(16):
         l2 = (8 - q) % 16
-        g = pb[q] if partner_block else [cf[q][3], cf[q][2], cf[q][1], cf[q][0]]
         if q <= 8:
             taps = [16 * (4 + j) + l2 for j in range(4)]
+            g = [cf[q][3], cf[q][2], cf[q][1], cf[q][0]]
         else:                                                              # padding step first (the lane reads +0 for the pixel), then taps ch = 4, 5, 6
             taps = [None] + [16 * (3 + j) + l2 for j in range(1, 4)]
+            g = [cf[q][3], cf[q][2], cf[q][1], cf[q][0]]
         for j in range(4):
             x = f32(0) if taps[j] is None else p[taps[j]]
             a[q] = fma(x, g[j], a[q])
@@ -107,35 +91,6 @@ def test_symmetric_lane_program_gives_the_reference_bits(seed):
         zero_sign_cases[0] += int(any(wc[l].view(np.uint32) != gc[l].view(np.uint32) for l in range(16)))
     if seed == 0:
         assert zero_sign_cases[0] > 0          # the sweep does reach the one case that differs (all products -0, c3 < 0)
-
-
-@pytest.mark.parametrize("seed", range(3))
-def test_partner_block_serves_non_palindromic_and_palindromic_rows(seed):
-    """A pixel step that contains a pixel of a non-palindromic bank row fetches the partner block for ALL its lanes (wave-uniform
-    branch): the lanes of that pixel need it, the lanes of the step's other pixels (palindromic rows) must get the same bits
-    from it as from their own four coefficients reversed."""
-    rng = np.random.default_rng(100 + seed)
-    for trial in range(300):
-        p = np.zeros(128, f32)
-        p[:121] = rng.integers(0, 1024, 121).astype(f32)
-        if trial % 5 == 0:
-            p[:121] *= rng.random(121) < 0.1
-        # arbitrary (non-palindromic) row: partner block required
-        f = np.zeros(128, f32)
-        f[:121] = (rng.standard_normal(121) * 0.1).astype(f32)
-        if trial % 3 == 0:                                                  # nearly a palindrome: a few taps off by an ulp, as in the shipped banks
-            f = palindrome_row(rng)
-            for k in rng.integers(0, 121, 2):
-                f[k] = np.nextafter(f[k], f32(1))
-        (wc, wv), (gc, gv) = reference_lanes(p, f), symmetric_lanes(p, f, partner_block=True)
-        for l in range(16):
-            assert wc[l].view(np.uint32) == gc[l].view(np.uint32) or (l >= 9 and wc[l] == 0 and gc[l] == 0), (trial, l)
-            assert wv[l].view(np.uint32) == gv[l].view(np.uint32) or (wv[l] == 0 and gv[l] == 0), (trial, l)
-        # palindromic row through the partner-block path: bit for bit what the four-load path computes
-        f = palindrome_row(rng, negatives=trial % 7 == 0)
-        (ac, av), (bc, bv) = symmetric_lanes(p, f, partner_block=False), symmetric_lanes(p, f, partner_block=True)
-        assert [x.view(np.uint32) for x in ac] == [x.view(np.uint32) for x in bc]
-        assert [x.view(np.uint32) for x in av] == [x.view(np.uint32) for x in bv]
 
 
 def test_partner_map_is_a_tree_automorphism():
@@ -204,17 +159,15 @@ def test_shared_tree_of_sixteen_steps_gives_each_lane_its_step():
 
 
 def test_lane_major_bank_layout_feeds_each_lane_its_chain():
-    """k_lane_major_bank (csrc/kernels_filter.h) lays every 128-float bank row out as 192 floats so that zmm lane l finds taps
-    l, 16 + l, ..., 112 + l as two runs of four floats -- float (ch >> 2) * 64 + 4 l + (ch & 3) holds tap 16 ch + l -- and, 512 B
-    after the first run, the partner block of the symmetric stage: the coefficients of steps 4..7 when the lane continues chain
-    (8 - l) & 15."""
-    row = np.arange(128, dtype=np.float32)                                  # tap index as the value
-    out = lane_major_row(row).astype(np.int32)
+    """k_lane_major_bank (csrc/kernels_filter.h) permutes every 128-float bank row so that zmm lane l finds taps l, 16 + l, ..., 112 + l
+    as two runs of four floats: float (ch >> 2) * 64 + 4 l + (ch & 3) holds tap 16 ch + l.  The filter stage reads run 0 (and run 1,
+    256 B further on, in the eight-load stage) with one 16-byte load each."""
+    row = np.arange(128, dtype=np.int32)                                   # tap index as the value
+    out = np.empty_like(row)
+    for e in range(128):                                                   # the kernel's index arithmetic
+        ch, l = e >> 4, e & 15
+        out[(ch >> 2) * 64 + l * 4 + (ch & 3)] = row[e]
     for l in range(16):
         assert list(out[4 * l:4 * l + 4]) == [16 * c + l for c in range(4)]
         assert list(out[64 + 4 * l:64 + 4 * l + 4]) == [16 * c + l for c in range(4, 8)]
-        l2 = (8 - l) % 16
-        want = [16 * c + l2 for c in range(4, 8)] if l <= 8 else [48 + l] + [16 * c + l2 for c in range(4, 7)]
-        assert list(out[128 + 4 * l:128 + 4 * l + 4]) == want
-        assert all(t <= 120 for t in want)                                  # real taps only (the padding step of l >= 9 multiplies a +0 sample)
-    assert sorted(out[:128]) == list(range(128))                            # a permutation: nothing lost, padding taps 121..127 included
+    assert sorted(out) == list(range(128))                                 # a permutation: nothing lost, padding taps 121..127 included

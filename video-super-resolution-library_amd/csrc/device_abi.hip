@@ -229,10 +229,10 @@ struct raisr_hip_ctx {
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
-    int sym_max_rows = -1;                     // ... chosen when at most this many rows are not (-1: a fifth of the bank's rows; RAISR_HIP_SYM_MAX_ROWS for A/B runs);
-                                               // a pixel step that meets one of them fetches the partner block as well (kernels_filter.h)
+    int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
-    bool defer = true;                         // uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist (RAISR_HIP_DEFER=0: in-tile)
+    bool defer = false;                        // RAISR_HIP_DEFER=1: uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist
+                                               // (bit-exact; measured slower on every configuration, docs/EXPERIMENTS.md: k_fix_ac costs more than the main kernel gains)
     FixAc fixac{};                             // ... the list (sized at configure: tiles of the largest pass x batch depth)
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     int fast = 0;                              // NON-bit-exact fast mode (raisr_hip_set_fast / RAISR_HIP_FAST): 1 = exact buckets, filter stage on the matrix cores; 2 = also keeps the approximate tensor's bucket where it is not certified
@@ -462,8 +462,12 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
         const int asym_rows = c->model[pass].asym_rows;
-        const int sym_rows_max = c->sym_max_rows >= 0 ? c->sym_max_rows : c->model[pass].h.hashkeys * c->model[pass].h.pixel_types / 5;
-        const bool sym = c->sym && asym_rows >= 0 && asym_rows <= sym_rows_max;   // symmetric filter stage of k_hashfilter_ac
+        bool sym = c->sym && asym_rows >= 0 && asym_rows <= c->sym_max_rows;   // symmetric filter stage of k_hashfilter_ac
+#ifdef RAISR_HIP_DEV
+        // TIMING PROBE, output wrong for pixels on non-palindromic rows: the symmetric stage whatever the bank, nothing redone -- what
+        // a free treatment of those rows would be worth (docs/EXPERIMENTS.md)
+        if (getenv("RAISR_HIP_SYM_IGNORE_ASYM")) { sym = true; P.asym = nullptr; }
+#endif
         if (c->fast || (c->fused && c->certify && c->split)) {
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
@@ -757,7 +761,7 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
-    if (const char* e = getenv("RAISR_HIP_DEFER")) c->defer = atoi(e) != 0;       // A/B switch: 0 = in-tile worklist instead of k_fix_ac
+    if (const char* e = getenv("RAISR_HIP_DEFER")) c->defer = atoi(e) != 0;       // A/B switch: 1 = k_fix_ac instead of the in-tile worklist
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);

@@ -13,26 +13,13 @@
 // Lane-major copy of the fp32 bank (built once per model): the filter stage's lane l reads taps l, 16 + l, ..., 112 + l of a
 // row; stored next to each other, the four coefficients the symmetric stage needs are ONE 16-byte load per pixel step instead
 // of four 4-byte loads -- the same bytes through the vector L1 with a quarter of the load instructions.
-// A row of the copy has kLmRow = 192 floats: [0, 64) taps ch = 0..3 of every lane, [64, 128) taps ch = 4..7 (eight-load stage,
-// plain_step), [128, 192) the PARTNER block of the symmetric stage: for lane l the four coefficients its steps 4..7 multiply
-// with when it continues chain l2 = (8 - l) & 15 -- f[64 + l2], f[80 + l2], f[96 + l2], f[112 + l2] for l <= 8; for l >= 9 (padding
-// step first) f[48 + l] (any finite value would do: it multiplies +0), f[64 + l2], f[80 + l2], f[96 + l2].  For a palindromic row
-// the block equals the lane's first four coefficients reversed, which is what the stage uses without loading it.
-constexpr unsigned kLmRow = 192;
+constexpr unsigned kLmRow = 128;          // floats per row of the lane-major bank
 __global__ __launch_bounds__(256) void k_lane_major_bank(const float* __restrict__ bank, float* __restrict__ out, unsigned n)
 {
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;          // n = rows * 192
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= n) return;
-    const unsigned r = e / kLmRow, k = e - r * kLmRow;
-    unsigned tap;
-    if (k < 128u) {
-        const unsigned l = (k & 63u) >> 2, ch = (k >> 6) * 4u + (k & 3u);
-        tap = 16u * ch + l;
-    } else {
-        const unsigned l = (k - 128u) >> 2, i = k & 3u, l2 = (8u - l) & 15u;
-        tap = l <= 8u ? 16u * (4u + i) + l2 : (i == 0u ? 48u + l : 16u * (3u + i) + l2);
-    }
-    out[e] = bank[r * 128u + tap];
+    const unsigned r = e >> 7, k = e & 127u, ch = k >> 4, l = k & 15u;
+    out[r * 128u + (ch >> 2) * 64u + l * 4u + (ch & 3u)] = bank[e];
 }
 
 template <int CTRL>
@@ -76,9 +63,7 @@ __device__ __forceinline__ float tree16(float acc)
 // a tree whose total is not zero, and a zero total fails the accept test either way (clamp_lo >= 0, checked at configure),
 // so the pixel keeps LR in both cases: every stored value has the reference's bits.  (tests/test_sym_filter_model.py
 // replays this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes are listed in
-// P.asym: a pixel step that contains a pixel of such a row fetches the partner block of the lane-major bank (one more 16-byte
-// load, k_lane_major_bank) and multiplies steps 4..7 with it -- for the step's other pixels the block holds the reversed first
-// four, so no selection is needed and every chain still runs its own FMAs in its own order.
+// P.asym; their pixels are redone with the full eight loads after the row's main loop.
 __device__ __forceinline__ float partner_xchg(float v)      // lane p of every row of 16 receives lane (8 - p) & 15
 {
     // (every lane of a row has a source lane: `old` is never used, so it is the source itself and no register is zeroed for it)
@@ -114,16 +99,16 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     // 32-bit buffer addressing of the filter bank (one descriptor per wave, built from uniform values).  The stage reads the
     // lane-major copy of the bank (k_lane_major_bank): the lane's coefficients of taps ch = 0..3 are one 16-byte load, ch = 4..7 the
     // one 256 B further on.
-    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.bank_lm), 0, P.bank_bytes / kTapsPad * kLmRow, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.bank_lm), 0, P.bank_bytes, 0x00020000);
     const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
-    const unsigned lane_off = (unsigned)(tcol * kLmRow + 4 * l) * 4u;      // byte offset of (type column part, zmm lane)
-    const unsigned bank_stride = (unsigned)(P.pixel_types * kLmRow * 4);   // bytes per hash bucket (<= 3072)
+    const unsigned lane_off = (unsigned)(tcol * kTapsPad + 4 * l) * 4u;      // byte offset of (type column part, zmm lane)
+    const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
     for (int row = 0; row < RPW; row++) {
         const int prow = RPW * w + row;
         const int r = r0 + prow;
-        const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kLmRow * 4) : 0u;
+        const unsigned trow_off = (P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 * kTapsPad * 4) : 0u;
         const unsigned row_lane_off = trow_off + lane_off;
         // LDS byte addresses of this lane's 8 taps (and the centre pixel) for step 0; step s adds the immediate 16*s
         const char* tap[8];
@@ -177,48 +162,34 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         float A16[16];
         // One step: the lane's chain.  No branch for a bucket byte of 0xFF (pixel not filtered): its offset lies past the bank, the
         // bounds-checked buffer loads return +0, v = 0 fails the accept test (clamp_lo >= 0, checked at configure) and the pixel keeps LR.
-        auto chain = [&](const float (&x)[8], const float (&q)[8], bool partner_block = false) -> float {
+        auto chain = [&](const float (&x)[8], const float (&q)[8]) -> float {
             float acc = x[0] * q[0];
             if (!SYM) {
 #pragma unroll
                 for (int ch = 1; ch < 8; ch++) acc = __builtin_fmaf(x[ch], q[ch], acc);
-            } else {                                            // q[0..3] only: the partner chain runs on the same four, backwards --
-                acc = __builtin_fmaf(x[1], q[1], acc);          // or, in a step with a pixel of a non-palindromic row (partner_block, wave-uniform),
-                acc = __builtin_fmaf(x[2], q[2], acc);          // on the partner block q[4..7] fetched for it
+            } else {                                            // q[0..3] only: the partner chain runs on the same four, backwards
+                acc = __builtin_fmaf(x[1], q[1], acc);
+                acc = __builtin_fmaf(x[2], q[2], acc);
                 acc = __builtin_fmaf(x[3], q[3], acc);
                 acc = partner_xchg(acc);
-                if (partner_block) {
-                    acc = __builtin_fmaf(x[4], q[4], acc);
-                    acc = __builtin_fmaf(x[5], q[5], acc);
-                    acc = __builtin_fmaf(x[6], q[6], acc);
-                    acc = __builtin_fmaf(x[7], q[7], acc);
-                } else {
-                    acc = __builtin_fmaf(x[4], q[3], acc);
-                    acc = __builtin_fmaf(x[5], q[2], acc);
-                    acc = __builtin_fmaf(x[6], q[1], acc);
-                    acc = __builtin_fmaf(x[7], q[0], acc);
-                }
+                acc = __builtin_fmaf(x[4], q[3], acc);
+                acc = __builtin_fmaf(x[5], q[2], acc);
+                acc = __builtin_fmaf(x[6], q[1], acc);
+                acc = __builtin_fmaf(x[7], q[0], acc);
             }
             return acc + row_ror<0x128>(acc);                   // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
         };
-        auto load_q = [&](unsigned hb, float (&q)[8], bool partner_block = false) {   // v_mad_u32_u24 for the offset (the 32x32 form is a slow 64-bit mad)
+        auto load_q = [&](unsigned hb, float (&q)[8]) {           // v_mad_u32_u24 for the offset (the 32x32 form is a slow 64-bit mad)
             const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
             const u32x4 fa = RAISR_BANK_F4(voff);
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) q[ch] = __uint_as_float(fa[ch]);
-            if (!SYM || partner_block) {                         // eight-load stage: the lane's own taps 4..7; symmetric stage: the partner block
-                const u32x4 fb = RAISR_BANK_F4(voff + (SYM ? 512u : 256u));
+            if (!SYM) {
+                const u32x4 fb = RAISR_BANK_F4(voff + 256u);
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++) q[4 + ch] = __uint_as_float(fb[ch]);
             }
         };
-        // symmetric stage: which of the row's 64 pixels (lane = tile column) sit on a non-palindromic bank row?  Bit 4 s + g <-> step s, group g.
-        unsigned long long am = 0;
-        if (SYM && P.asym) {
-            const unsigned hrow = sH[prow * TW + lane];
-            const unsigned key = hrow * (unsigned)P.pixel_types + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
-            am = __ballot(hrow != 0xFFu && ((P.asym[key >> 5] >> (key & 31u)) & 1u));
-        }
 #if defined(RAISR_HIP_DEV) && (defined(RAISR_EXP_COEF_REUSE) || defined(RAISR_EXP_NO_WINDOW))
         // TIMING PROBES, output wrong (docs/EXPERIMENTS.md I.4), on the compiler's own schedule.  RAISR_EXP_COEF_REUSE = n: coefficients
         // are fetched for every n-th step only and reused for the steps between -- what any scheme that shares coefficient rows
@@ -245,39 +216,31 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             // symmetric stage +0.8 % with one or two pairs of look-ahead, +0 % with three (r04_call19); the eight-load stage +1 %
             // with 4-byte loads and +3.6-4.7 % with the two 16-byte loads (C1, C5; r04_call23), which on the compiler's schedule
             // were 4 % SLOWER than eight 4-byte loads (r04_call18).  Same operations on the same operands.
-            // MIXED (symmetric stage, rows with pixels on non-palindromic bank rows): a step whose four pixels include one fetches
-            // the partner block as well -- a wave-uniform branch per step on the row's mask.
             constexpr int AHEAD = 1;
-            auto steps = [&](auto mixed_tag) {
-                constexpr bool MIXED = decltype(mixed_tag)::value;
-                float Q[16][8];
-                float X[16][8];
-                unsigned Hh[16];
-                auto pb = [&](int s) -> bool { return MIXED && ((am >> (4 * s)) & 0xFull) != 0; };
-                auto issue_h = [&](int s) { Hh[s] = sH[prow * TW + 4 * s + g]; };
-                auto issue_x = [&](int s) {
+            float Q[16][8];
+            float X[16][8];
+            unsigned Hh[16];
+            auto issue_h = [&](int s) { Hh[s] = sH[prow * TW + 4 * s + g]; };
+            auto issue_x = [&](int s) {
 #pragma unroll
-                    for (int ch = 0; ch < 8; ch++) X[s][ch] = RAISR_LDS_F(tap[ch], s);
-                };
-#pragma unroll
-                for (int s = 0; s < 2 * AHEAD + 2; s++) issue_h(s);
-#pragma unroll
-                for (int s = 0; s < 2 * AHEAD; s++) load_q(Hh[s], Q[s], pb(s));
-                issue_x(0); issue_x(1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    if (p + AHEAD < 8) { load_q(Hh[2 * (p + AHEAD)], Q[2 * (p + AHEAD)], pb(2 * (p + AHEAD))); load_q(Hh[2 * (p + AHEAD) + 1], Q[2 * (p + AHEAD) + 1], pb(2 * (p + AHEAD) + 1)); }
-                    if (p + AHEAD + 1 < 8) { issue_h(2 * (p + AHEAD + 1)); issue_h(2 * (p + AHEAD + 1) + 1); }
-                    if (p + 1 < 8) { issue_x(2 * p + 2); issue_x(2 * p + 3); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    A16[2 * p] = chain(X[2 * p], Q[2 * p], pb(2 * p));
-                    A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1], pb(2 * p + 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int ch = 0; ch < 8; ch++) X[s][ch] = RAISR_LDS_F(tap[ch], s);
             };
-            if (SYM && am != 0) steps(std::true_type{});
-            else steps(std::false_type{});
+#pragma unroll
+            for (int s = 0; s < 2 * AHEAD + 2; s++) issue_h(s);
+#pragma unroll
+            for (int s = 0; s < 2 * AHEAD; s++) load_q(Hh[s], Q[s]);
+            issue_x(0); issue_x(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                if (p + AHEAD < 8) { load_q(Hh[2 * (p + AHEAD)], Q[2 * (p + AHEAD)]); load_q(Hh[2 * (p + AHEAD) + 1], Q[2 * (p + AHEAD) + 1]); }
+                if (p + AHEAD + 1 < 8) { issue_h(2 * (p + AHEAD + 1)); issue_h(2 * (p + AHEAD + 1) + 1); }
+                if (p + 1 < 8) { issue_x(2 * p + 2); issue_x(2 * p + 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                A16[2 * p] = chain(X[2 * p], Q[2 * p]);
+                A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #endif
 #define RAISR_MERGE(dst, src, mask) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask))
@@ -307,6 +270,20 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         const int sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);     // the step whose pixel this lane keeps
         float keep = RAISR_LDS_F(ctr, sl);
         if (v > P.lo && v < P.hi) keep = v;
+        if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
+            const unsigned hrow = sH[prow * TW + lane];
+            const unsigned key = hrow * (unsigned)P.pixel_types + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
+            const bool af = hrow != 0xFFu && ((P.asym[key >> 5] >> (key & 31u)) & 1u);
+            const unsigned long long am = __ballot(af);
+            if (am) {
+#pragma unroll 1
+                for (int s = 0; s < 16; s++) {
+                    if (((am >> (4 * s)) & 0xFull) == 0) continue;
+                    const float v = plain_step(s, sH[prow * TW + 4 * s + g]);
+                    if (s == sl && ((am >> (4 * s + g)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
+                }
+            }
+        }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
             for (int s = 0; s < 16; s++) {

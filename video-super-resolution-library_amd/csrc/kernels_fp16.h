@@ -545,13 +545,19 @@ __global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ l
     constexpr int R = 4, TW = 64, TH = 16;
     constexpr int LW = 77, LH = TH + 12;
     constexpr int kGBytes = (TH + 9) * 74 * 8, kTabBytes = 2048 * 2, kPairBytes = 26 * LW * 4;
-    static_assert(2 * kPairBytes <= kGBytes + kTabBytes, "the pair windows fit the hash stage's region");
+    // Array B starts 15 dwords after array A's end: with the arrays back to back (round 4), three of the four tap-pair chunks had
+    // a lane on array A and a lane on array B of every 32-lane half hit the same LDS bank with different addresses (26 * 77 = 18
+    // mod 32 puts B's columns 6..10 of one patch row on A's columns 0..5 of another): 6 extra LDS cycles on 8 per step, the bulk of
+    // the kernel's SQ_LDS_BANK_CONFLICT (23.7 % of its LDS cycles).  Offsets 15 and 27 are the conflict-free ones at row stride 77
+    // (exhaustive over strides 74..90 and offsets 0..39: tests/test_fp16_pair_windows.py replays the bank arithmetic).
+    constexpr int kPairPad = 15 * 4;
+    static_assert(2 * kPairBytes + kPairPad <= kGBytes + kTabBytes, "the pair windows fit the hash stage's region");
     __shared__ hf sL[LH * LW];
     __shared__ __attribute__((aligned(16))) unsigned char sRegion[kGBytes + kTabBytes];
     uint2* sG = reinterpret_cast<uint2*>(sRegion);
     uint16_t* sTab = reinterpret_cast<uint16_t*>(sRegion + kGBytes);
     uint32_t* sPA = reinterpret_cast<uint32_t*>(sRegion);
-    uint32_t* sPB = reinterpret_cast<uint32_t*>(sRegion + kPairBytes);
+    uint32_t* sPB = reinterpret_cast<uint32_t*>(sRegion + kPairBytes + kPairPad);
     __shared__ uint8_t sH[TH * TW];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
