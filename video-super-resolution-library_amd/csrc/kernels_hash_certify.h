@@ -71,7 +71,8 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     const float ab = __builtin_fabsf(b);
     const float ay = ab + 1e-10f;
     const float xx = m >= 0.0f ? m + s : bb * __builtin_amdgcn_rcpf(s - m);        // (s - m)(s + m) = b^2
-    const float E_ay = __builtin_fmaf(U1, ay, E_b);
+    const float E_ay = __builtin_fmaf(2.0f * U1, ay, E_b);        // |b| vs |b'|, and the rounding of "+ 1e-10" on EITHER side (round 5: was 1 u, covered
+                                                                    // only by slack elsewhere -- found by tests/test_certify_interval.py)
     const float xpa = xx + ay;
     const float D = xpa - (E_L + E_ay);
     const float rr = (xx - ay) * __builtin_amdgcn_rcpf(xpa);
