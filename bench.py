@@ -94,6 +94,10 @@ def parse():
     ap.add_argument("--stream", action="store_true",
                     help="headline value from HOST-resident frames streamed through the pinned-ring batch entry "
                          "(PCIe inclusive; for the C5 600-frame stream use --config C5 --stream --frames-per-step 600 --steps 1)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives --gpus N devices through the library's multi-device ring (raisr_hip_stream_create_multi: frame i "
+                         "-> device i mod N, in-order collection, model handed to the devices by the in-process RCCL broadcast); host-resident "
+                         "frames, PCIe inclusive.  The C++-host counterpart of the torchrun launch; prints its own JSON line.")
     return ap.parse_args()
 
 
@@ -510,7 +514,7 @@ def end_to_end_leg(R, wl, n_frames, gpu):
                                         "memory to an asynchronous copy and never page-locks memory it does not own unless RAISR_HIP_PIN=1"}}
 
 
-def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):
+def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None, lanes_per_device=4):
     """Host planes -> host planes through the library's ring (raisr_hip_stream_*): uploads, kernels and downloads of
     neighbouring frames overlap.  The planes are page-locked (raisr_hip_host_alloc), as a host with its own buffer pool would
     hand them over.  Returns the JSON object (and, for tests, copies of the first `collect_outputs` Y outputs)."""
@@ -519,7 +523,8 @@ def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):
     cw, ch = wl.in_w // 2, wl.in_h // 2
     ratio = wl.out_w / wl.in_w
     ocw, och = int(cw * ratio), int(ch * ratio)
-    depth = 4
+    devices = list(gpu) if isinstance(gpu, (list, tuple)) else None        # a list: the multi-device ring, one host thread
+    depth = lanes_per_device * (len(devices) if devices else 1)             # frames in flight
     dt = ys_np[0].dtype
     pins = []
 
@@ -535,8 +540,9 @@ def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):
     pins.extend(frames_out)
     outs = [(f.y, f.u, f.v) for f in frames_out]
     st = R.RaisrStream(gpu, wl.folder, wl.in_w, wl.in_h, wl.out_w, wl.out_h, bits=wl.bits, passes=wl.passes, mode=wl.mode,
-                       hash_variant=wl.asm, chroma=(cw, ch, ocw, och), depth=depth,
+                       hash_variant=wl.asm, chroma=(cw, ch, ocw, och), depth=lanes_per_device,
                        blobs=None if blobs is None else [(b.data_ptr(), b.numel()) for b in blobs])    # the broadcast blob, not the files
+    assert st.depth == depth
     kept = []
     try:
         for warm in (True, False):
@@ -569,6 +575,9 @@ def stream_leg(R, wl, gpu, n_frames, collect_outputs=0, blobs=None):
     res = {"value": round(fps * wl.out_w * wl.out_h / 1e6, 2), "unit": "MP/s", "fps": round(fps, 2), "frames": n_frames,
            "what": f"host->host yuv420p through the stream ring (depth {depth}: H2D of frame n+1 and D2H of frame n-1 overlap frame n's "
                    "kernels; page-locked planes, Y+U+V, PCIe inclusive)"}
+    if devices:
+        res["devices"] = devices
+        res["what"] += f"; ONE process, {len(devices)} device slot(s) x {lanes_per_device} lanes, frame i -> device i mod {len(devices)}"
     return (res, kept) if collect_outputs else res
 
 
@@ -605,7 +614,7 @@ def certify_leg(R, wl, gpu, blobs, frames):
         return {"applies": False, "why": "binary16 numerics: every pixel takes the exact path (DESIGN.md s5: no sound bound for binary16 accumulation)"}
     res = {}
     for check in (False, True):
-        d = R.RaisrDevice(gpu)
+        d = R.RaisrDevice(gpu, hooks=True)                     # the self-check hooks live in the test-hooks flavour of the library (same kernels)
         try:
             for p in range(wl.passes):
                 d.set_model_blob_device(p, blobs[p].data_ptr(), blobs[p].numel())
@@ -651,10 +660,41 @@ def config_leg(R, torch, name, gpu, load_blobs, lanes_n, n_frames, fence, kind, 
             "certify": certify_leg(R, w, gpu, b, frames[:4])}
 
 
+def single_process_main(args):
+    """--single-process: the multi-device ring of the C ABI (what a C++ host links: raisr_hip_stream_create_multi), N devices, one
+    process, one thread.  K steps of frames_per_step host-resident frames, W warm-up steps; value = frames / wall time, PCIe inclusive.
+    No torch.distributed: the model reaches the devices by raisr_hip_broadcast_model_blob_devices inside the library."""
+    import raisr_hip as R
+    wl = Workload(args.config, args.passes or None)
+    have = R.lib().raisr_hip_device_count()
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
+    devs = os.environ.get("RAISR_BENCH_DEVICES")                       # e.g. "0,0": one GPU standing in for two (plumbing tests)
+    devices = [int(t) for t in devs.split(",")] if devs else list(range(args.gpus))
+    if len(devices) != args.gpus or any(d >= have for d in devices):
+        raise SystemExit(f"bench.py --single-process: --gpus {args.gpus} needs {args.gpus} devices, found {have}")
+    nf = min(args.frames_per_step, 256) if args.frames_per_step == 768 else args.frames_per_step      # PCIe-bound: a default run stays short
+    if args.warmup:
+        stream_leg(R, wl, devices, max(8, nf // 4))
+    res = stream_leg(R, wl, devices, nf * args.steps)
+    dt = nf * args.steps / res["fps"]
+    line = {"metric": "megapixels/sec (Y-plane)", "value": res["value"], "unit": "MP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if wl.asm == 5 else "f32", "data": "synthetic",
+            "mode": "single process, multi-device ring, host-resident frames (PCIe inclusive) -- NOT the headline metric (that one keeps frames in HBM)",
+            "config": {"workload": f"{wl.name}: {wl.desc}", "frames_per_step": nf, "fps": res["fps"], "devices": devices,
+                       "parallelism": f"one process, frame i -> device i mod {args.gpus}, 4 lanes per device"},
+            "stream": res}
+    print(json.dumps(line))
+    return 0
+
+
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.single_process:
+        return single_process_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         respawn_ranks(args)                                   # does not return
     wl = Workload(args.config, args.passes or None)

@@ -52,7 +52,7 @@ def frames(i, w, h, bits):
 
 tot = {}
 for key, fold, w, h, ow, oh, bits, passes, mode, asm, full, nn in MATRIX:
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=True)
     dev.set_model_from_folder(fold, bits, passes)
     dev.configure(w, h, ow, oh, bits=bits, full_range=full, passes=passes, mode=mode, hash_variant=asm)
     dev.certify_debug(True, True)

@@ -70,8 +70,11 @@ if pmc:
               "  these row-coalesced loads too, so FETCH_SIZE is doubled below, as the guide prescribes.", ""]
     # derived: VALU issue rate and LDS conflict share, per kernel, from the isolated (--lanes 1) durations of bench.py
     iso = {}
+    fpl = 1                                                   # frames per launch of the profiled command (bench.py batches outputs <= 1080p by 8)
     try:
-        iso = json.loads(open(ev).read().strip().splitlines()[-1]).get("kernels_isolated_ms", {})
+        jj = json.loads(open(ev).read().strip().splitlines()[-1])
+        iso = jj.get("kernels_isolated_ms", {})
+        fpl = int(jj.get("config", {}).get("frames_per_launch", 1)) or 1
     except Exception:
         pass
     alias = {"k_resize2x": "k_resize"}
@@ -79,12 +82,14 @@ if pmc:
     for k, v in pmc.items():
         t_ms = iso.get(alias.get(k, k))
         if t_ms and "SQ_INSTS_VALU" in v:
-            rate = v["SQ_INSTS_VALU"] / (t_ms * 1e-3) / 1e9
+            # the counters are per LAUNCH (fpl frames), the isolated time is per FRAME: bring both to one frame (the round-4 summaries
+            # of C1 / C4 divided 8-frame counters by a single-frame time: "341 %" of the probe rate)
+            rate = v["SQ_INSTS_VALU"] / fpl / (t_ms * 1e-3) / 1e9
             conf = 100.0 * v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"] if v.get("SQ_LDS_IDX_ACTIVE") else 0.0
             l2 = 100.0 * v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 1.0))
-            rows.append(f"| {k} | {t_ms * 1e3:.1f} | {v['SQ_INSTS_VALU'] / 1e6:.1f} | {rate:.0f} | {100 * rate / 911:.0f} % | {conf:.1f} % | {l2:.1f} % |")
+            rows.append(f"| {k} | {t_ms * 1e3:.1f} | {v['SQ_INSTS_VALU'] / fpl / 1e6:.1f} | {rate:.0f} | {100 * rate / 911:.0f} % | {conf:.1f} % | {l2:.1f} % |")
     if rows:
-        lines += ["## Derived (isolated launch, one lane)", "",
+        lines += [f"## Derived (per frame: counters of a {fpl}-frame launch / {fpl}, isolated single-frame launch time, one lane)", "",
                   "| kernel | isolated us | VALU wave-inst (M) | G wave-inst/s | of the 911 G/s `v_fma_f32` probe rate | LDS cycles lost to bank conflicts | L2 hit rate |",
                   "|---|---|---|---|---|---|---|"] + rows + ["",
                   "(packed-fp32 instructions count once here but occupy two issue slots, so the tensor-heavy kernel's slot utilisation is",

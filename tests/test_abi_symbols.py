@@ -7,21 +7,40 @@ import re
 from common import ROOT
 
 
-def _declared():
+def _declared(headers):
     names = set()
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "include", "raisr", "RaisrHandler.h")):
+    for h in headers:
         txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         names |= set(re.findall(r"\b(raisr_hip_[a-z_0-9]+|RNLHandler_[A-Za-z]+)\s*\(", txt))
     return names
 
 
+PRODUCT_HEADERS = [os.path.join(ROOT, "include", "raisr_hip.h"), os.path.join(ROOT, "include", "raisr", "RaisrHandler.h")]
+DEBUG_HEADER = os.path.join(ROOT, "include", "raisr_hip_debug.h")
+
+
 def test_every_declared_symbol_is_exported():
     import raisr_hip as R
     R.build()
+    assert sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) == sorted([PRODUCT_HEADERS[0], DEBUG_HEADER])
     lib = ctypes.CDLL(os.path.join(ROOT, "video-super-resolution-library_amd", "libraisr_hip.so"))
-    decl = _declared()
+    decl = _declared(PRODUCT_HEADERS)
     assert len(decl) >= 20
     missing = [n for n in sorted(decl) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_test_hooks_live_in_their_own_library_only():
+    """include/raisr_hip_debug.h (introspection for tests, comparison pipelines) is served by libraisr_hip_testhooks.so; the product
+    library exports none of it.  (raisr_hip_dev_phase_stats: development builds only.)"""
+    pkg = os.path.join(ROOT, "video-super-resolution-library_amd")
+    product = ctypes.CDLL(os.path.join(pkg, "libraisr_hip.so"))
+    hooks = ctypes.CDLL(os.path.join(pkg, "libraisr_hip_testhooks.so"))
+    dbg = _declared([DEBUG_HEADER]) - _declared(PRODUCT_HEADERS)
+    assert len(dbg) >= 8
+    assert [n for n in sorted(dbg) if hasattr(product, n)] == []
+    assert [n for n in sorted(dbg - {"raisr_hip_dev_phase_stats"}) if not hasattr(hooks, n)] == []
+    missing = [n for n in sorted(_declared(PRODUCT_HEADERS)) if not hasattr(hooks, n)]      # ... and it is a superset of the product ABI
     assert not missing, missing
 
 

@@ -109,3 +109,15 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_single_process_multi_device_ring():
+    """`bench.py --gpus N --single-process`: ONE process drives N device slots through raisr_hip_stream_create_multi (the C++-host
+    counterpart of the torchrun launch).  One GPU here: RAISR_BENCH_DEVICES=0,0 lists it twice."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "2", "--warmup", "1", "--frames-per-step", "24",
+           "--config", "C1"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, RAISR_BENCH_DEVICES="0,0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _one_json_line(out.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["devices"] == [0, 0] and j["value"] > 0 and j["unit"] == "MP/s"
+    assert "single process" in j["mode"] and j["stream"]["frames"] == 48

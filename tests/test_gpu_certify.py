@@ -45,7 +45,7 @@ def test_certified_buckets_equal_exact_buckets(case):
     for kind, y in _frames(w, h, bits).items():
         ref = oracle_y(y, case)
         for check in (True, False):      # self-check mode (all pixels through both paths), then production mode
-            dev = R.RaisrDevice(0)
+            dev = R.RaisrDevice(0, hooks=True)
             try:
                 dev.set_model_from_folder(folder(fold), bits, passes)
                 dev.configure(w, h, ow, oh, bits=bits, full_range=full, passes=passes, mode=mode, hash_variant=asm)
@@ -74,7 +74,7 @@ def test_exact_kernel_still_selectable(monkeypatch):
     monkeypatch.setenv("RAISR_HIP_CERTIFY", "0")
     case = CASES[0]
     y = synth.natural_y(200, 120, 8, seed=5)
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=True)
     try:
         dev.set_model_from_folder(folder(case[1]), 8, 1)
         dev.configure(200, 120, 400, 240, bits=8, passes=1, hash_variant=2)
@@ -98,7 +98,7 @@ def test_full_size_self_check_c2():
         y = fr[kind]
         ref = oracle_y(y, case)
         for check in (True, False):
-            dev = R.RaisrDevice(0)
+            dev = R.RaisrDevice(0, hooks=True)
             try:
                 dev.set_model_from_folder(folder(case[1]), 8, 1)
                 dev.configure(w, h, 2 * w, 2 * h, bits=8, passes=1, hash_variant=2)
@@ -147,7 +147,7 @@ def test_certified_buckets_hold_on_the_whole_error_box(flavour):
     d = l1 * sth * sth + l2 * cth * cth
     b = (l1 - l2) * sth * cth
     abd = np.stack([a, b, d], 1).astype(np.float32)
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=True)
     try:
         dev.set_model_from_folder(folder(fold), 8, 1)
         dev.configure(64, 64, 128, 128, bits=8)
@@ -187,7 +187,7 @@ def test_zero_tensor_bucket_is_stable_across_context_lifetimes():
         import torch
         junk.append(torch.full((1 + it,), float("nan"), device="cuda"))      # dirty a few small device allocations in between
         y, ref = frames[it % 2], refs[it % 2]
-        dev = R.RaisrDevice(0)
+        dev = R.RaisrDevice(0, hooks=True)
         try:
             dev.set_model_from_folder(folder(case[1]), 10, 2)
             dev.configure(96, 64, 192, 128, bits=10, passes=2, mode=2, hash_variant=2)

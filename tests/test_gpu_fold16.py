@@ -22,7 +22,7 @@ def test_folded_thresholds_equal_the_divisions(folder, bits):
     passes = 2 if glob.glob(os.path.join(folder, f"filterbin_*_{bits}_2")) else 1
     if not glob.glob(os.path.join(folder, f"filterbin_*_{bits}")):
         pytest.skip("no model for this bit depth")
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=True)
     try:
         dev.set_model_from_folder(folder, bits, passes)
         for p in range(passes):

@@ -22,7 +22,7 @@ def _hip(y, case, stages=False):
     _, fold, (rn, rd), bits, passes, mode, asm, full = case
     h, w = y.shape
     ow, oh = w * rn // rd, h * rn // rd
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=stages)                    # per-stage dumps: the test-hooks flavour (include/raisr_hip_debug.h)
     try:
         dev.set_model_from_folder(folder(fold), bits, passes)
         dev.configure(w, h, ow, oh, bits=bits, full_range=full, passes=passes, mode=mode, hash_variant=asm)

@@ -59,7 +59,7 @@ def test_device_hash_matches_oracle_on_adversarial_triples(fold, bits):
     import oracle_py as O
     import raisr_hip as R
     abd = _triples(1234 + bits)
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=True)
     try:
         dev.set_model_from_folder(folder(fold), bits, 1)
         for flavour, avx2 in ((R.HASH_AVX512, 0), (R.HASH_AVX2, 1)):

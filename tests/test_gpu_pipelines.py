@@ -1,4 +1,6 @@
-"""-m gpu: EVERY pipeline a user can select through the environment produces the oracle's bits.
+"""-m gpu: EVERY pipeline that can be selected through the environment produces the oracle's bits -- the product library's (default,
+RAISR_HIP_FUSED=0, RAISR_HIP_CERTIFY=0, RAISR_HIP_CHUNKS) on the product library, the comparison pipelines (RAISR_HIP_SPLIT,
+RAISR_HIP_DEFER) and every self-check run on the test-hooks flavour (libraisr_hip_testhooks.so), where they live.
 
 The library reads RAISR_HIP_SPLIT / RAISR_HIP_LDS_FILTER / RAISR_HIP_FUSED / RAISR_HIP_CERTIFY when a context is created
 (csrc/device_abi.hip: create_impl).  The default is the fused certified kernel k_hashfilter_ac; the alternatives chain other
@@ -23,8 +25,12 @@ PIPELINES = {
     # host-plane entry: last pass in row ranges, finished rows downloaded while the next range is computed
     "chunks3": {"RAISR_HIP_CHUNKS": "3"},
     "chunks8": {"RAISR_HIP_CHUNKS": "8"},
+    # the exact path of the uncertified pixels as its own kernel (k_hashfilter_ac<DEFER> + k_fix_ac): round-5 experiment, kept for comparisons
+    "defer": {"RAISR_HIP_DEFER": "1"},
+    "defer_chunks3": {"RAISR_HIP_DEFER": "1", "RAISR_HIP_CHUNKS": "3"},
 }
 CERTIFIED = ("default", "split_lds", "split_l1", "chunks3")
+HOOKS_ONLY = ("split_lds", "split_l1", "defer", "defer_chunks3")
 
 # (id, folder, ratio, bits, passes, mode, asm, full)
 CASES = [
@@ -43,11 +49,11 @@ def _frames(w, h, bits):
             "checker": synth.checker_y(w, h, bits), "constant": synth.constant_y(w, h, bits)}
 
 
-def _run(R, y, case, check=None, blending=None):
+def _run(R, y, case, check=None, blending=None, hooks=False):
     _, fold, (rn, rd), bits, passes, mode, asm, full = case
     h, w = y.shape
     ow, oh = w * rn // rd, h * rn // rd
-    dev = R.RaisrDevice(0)                                   # the environment is read here
+    dev = R.RaisrDevice(0, hooks=hooks or check is not None)              # the environment is read here
     try:
         dev.set_model_from_folder(folder(fold), bits, passes)
         kw = {} if blending is None else {"blending": blending}
@@ -66,7 +72,7 @@ def _run(R, y, case, check=None, blending=None):
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_every_selectable_pipeline_is_bit_exact(pipeline, case, monkeypatch):
     import raisr_hip as R
-    for k in ("RAISR_HIP_SPLIT", "RAISR_HIP_LDS_FILTER", "RAISR_HIP_FUSED", "RAISR_HIP_CERTIFY", "RAISR_HIP_FAST", "RAISR_HIP_CHUNKS"):
+    for k in ("RAISR_HIP_SPLIT", "RAISR_HIP_LDS_FILTER", "RAISR_HIP_FUSED", "RAISR_HIP_CERTIFY", "RAISR_HIP_FAST", "RAISR_HIP_CHUNKS", "RAISR_HIP_DEFER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in PIPELINES[pipeline].items():
         monkeypatch.setenv(k, v)
@@ -75,11 +81,11 @@ def test_every_selectable_pipeline_is_bit_exact(pipeline, case, monkeypatch):
     for (w, h) in ((290, 150), (70, 41)):
         for kind, y in _frames(w, h, bits).items():
             ref = oracle_y(y, case)
-            out, _ = _run(R, y, case)
+            out, _ = _run(R, y, case, hooks=pipeline in HOOKS_ONLY)
             bad = np.argwhere(out != ref)
             assert bad.size == 0, f"{pipeline} {case[0]} {kind} {w}x{h}: {len(bad)} mismatching pixels, first {bad[:4].tolist()}"
             if pipeline in CERTIFIED and asm != 5 and (w, h) == (290, 150):
-                out2, st = _run(R, y, case, check=True)      # self-check: every pixel also through the exact path
+                out2, st = _run(R, y, case, check=True, hooks=True)      # self-check: every pixel also through the exact path
                 assert st["pixels"] > 0 and st["mismatches"] == 0, (pipeline, case[0], kind, st)
                 assert np.array_equal(out2, ref), (pipeline, case[0], kind, "self-check output")
 
@@ -101,7 +107,7 @@ def test_pipelines_16bit_and_randomness(pipeline, monkeypatch, tmp_path):
     p1 = O.make_pass(O.Model(folder(case[1]), 8, 1), 8, False, 2, O.BLEND_RANDOMNESS)
     preset = np.full((2 * h, 2 * w), 77, np.uint8)
     ref = O.run_pass(O.resize(y, 2 * w, 2 * h), p1, preset=preset).astype(np.uint8)
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=pipeline in HOOKS_ONLY)
     try:
         dev.set_model_from_folder(folder(case[1]), 8, 1)
         dev.configure(w, h, 2 * w, 2 * h, bits=8, passes=1, mode=1, hash_variant=2, blending=R.BLEND_RANDOMNESS)
@@ -119,7 +125,7 @@ def test_pipelines_16bit_and_randomness(pipeline, monkeypatch, tmp_path):
     y16 = (synth.natural_y(w, h, 10, seed=5).astype(np.uint32) * 64).astype(np.uint16)
     p16 = O.make_pass(O.Model(str(dst), 16, 1), 16, False, 2)
     ref16 = O.process_y(y16, 2 * w, 2 * h, p16, None, 1, 1).astype(np.uint16)
-    dev = R.RaisrDevice(0)
+    dev = R.RaisrDevice(0, hooks=pipeline in HOOKS_ONLY)
     try:
         dev.set_model_from_folder(str(dst), 16, 1)
         dev.configure(w, h, 2 * w, 2 * h, bits=16, passes=1, mode=1, hash_variant=2)

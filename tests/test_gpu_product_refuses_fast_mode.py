@@ -39,3 +39,28 @@ def test_development_build_keeps_the_mode_within_its_bounds():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_fast_mode.py"), "-x", "-q", "-m", "gpu"], env=env,
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("var", ["RAISR_HIP_SPLIT", "RAISR_HIP_DEFER"])
+def test_comparison_pipelines_are_refused_by_the_product_library(var, monkeypatch):
+    """RAISR_HIP_SPLIT / RAISR_HIP_DEFER select pipelines that exist in the test-hooks flavour only (include/raisr_hip_debug.h): the
+    product library says so instead of silently running its own pipeline; the hooks flavour honours them (tests/test_gpu_pipelines.py)."""
+    import raisr_hip as R
+    monkeypatch.setenv(var, "1")
+    with pytest.raises(RuntimeError, match="RAISR_HIP_TESTHOOKS"):
+        R.RaisrDevice(0)
+    R.RaisrDevice(0, hooks=True).close()
+    monkeypatch.setenv(var, "0")
+    R.RaisrDevice(0).close()                                  # "off" is always accepted
+
+
+def test_debug_hooks_are_not_in_the_product_library():
+    import raisr_hip as R
+    dev = R.RaisrDevice(0)
+    try:
+        with pytest.raises(RuntimeError, match="hooks=True"):
+            dev.keep_stages(True)
+        with pytest.raises(RuntimeError, match="hooks=True"):
+            dev.certify_debug(True, False)
+    finally:
+        dev.close()

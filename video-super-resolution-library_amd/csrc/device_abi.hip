@@ -11,8 +11,12 @@
 //   kernels_fp16.h          k_hashfilter16, k_blend16, ...   the AVX512-FP16 numerics in binary16 (Raisr_AVX512FP16.cpp)
 //   kernels_blend.h         k_blend, k_blend_rand            census-transform blend, clamp, narrow, borders (Raisr_AVX256.cpp:68-166,
 //                                                            Raisr.cpp:999-1028,1252-1265)
-//   kernels_split.h         k_hash_ac, k_fix_*, k_filter_lds16   selectable alternative: un-fused pipeline, filter bank in LDS (RAISR_HIP_SPLIT=1)
-//   kernels_fast.h          k_filter_mfma                    opt-in, NOT bit-exact: filter stage on the matrix cores
+// builds with -DRAISR_HIP_TESTHOOKS (libraisr_hip_testhooks.so: the test suite's flavour) add the hooks of include/raisr_hip_debug.h and
+//   kernels_split.h         k_hash_ac, k_fix_*, k_filter_lds16   comparison pipeline: un-fused, filter bank in LDS (RAISR_HIP_SPLIT=1)
+//   kernels_fix.h           k_fix_ac                         comparison pipeline: exact path of the uncertified pixels as its own kernel (RAISR_HIP_DEFER=1)
+// development builds (-DRAISR_HIP_DEV) furthermore
+//   kernels_fast.h          k_filter_mfma                    NOT bit-exact: filter stage on the matrix cores (measured slower: rejected)
+//   kernels_probes.h, kernels_experiments.h                  timing probes (output wrong) and rejected experiments (docs/EXPERIMENTS.md)
 //
 // Pipeline per RAISR pass (whole-frame semantics of the reference's processSegment(), Library/Raisr.cpp:890-1289, run with
 // threadcount=1):  k_resize -> k_hashfilter_ac -> k_blend.
@@ -21,9 +25,9 @@
 // the cited reference lines ("strict source" semantics).  This file MUST be built with -ffp-contract=off and without fast-math;
 // FMAs appear only where the reference has an explicit fmadd intrinsic.
 //
-// Design notes (MI355X): the work is fp32-VALU bound (~1.3 kFLOP per output pixel per pass against ~1.25 compulsory HBM bytes)
-// and, in the filter stage, vector-L1 bound (512 B of coefficients per pixel), so the kernels are organised around
-// VALU/LDS/L1 efficiency.
+// Design notes (MI355X): ~1.3 kFLOP per output pixel per pass against ~1.25 compulsory HBM bytes: not an HBM-bound path.  The main
+// kernel is instruction-issue bound at the 16 waves per CU its LDS and registers allow, with VALU, LDS and vector L1 each 40-60 % busy,
+// so the kernels are organised around instruction count and VALU / LDS / L1 efficiency.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -38,6 +42,12 @@
 #include <vector>
 
 #include "../../include/raisr_hip.h"
+#if defined(RAISR_HIP_DEV) && !defined(RAISR_HIP_TESTHOOKS)
+#define RAISR_HIP_TESTHOOKS 1         /* development builds carry the test hooks as well */
+#endif
+#ifdef RAISR_HIP_TESTHOOKS
+#include "../../include/raisr_hip_debug.h"
+#endif
 #include "host_copy.h"               // RowCopyPool, HostBounce: pageable host planes go through page-locked bounce memory
 #include "x86_approx_tables.h"
 #include "x86_approx_dev.h"
@@ -57,12 +67,19 @@ namespace {
 #include "kernels_hash.h"            // hash_px_*, hash_phase, k_hash
 #include "kernels_hash_certify.h"    // approx_hash, tensor_ac, hash_phase_ac
 #include "kernels_fp16.h"            // binary16 pipeline: k_hashfilter16, k_hash16, k_filter16, k_blend16
+#ifdef RAISR_HIP_DEV
+#include "kernels_probes.h"          // timing probes of the filter stage (output wrong): hooks that kernels_filter.h expands
+#endif
 #include "kernels_filter.h"          // filter_phase, k_filter, k_hashfilter, k_hashfilter_ac
+#ifdef RAISR_HIP_TESTHOOKS           /* comparison pipelines (RAISR_HIP_DEFER, RAISR_HIP_SPLIT): test-hooks builds only */
 #include "kernels_fix.h"             // k_fix_ac: deferred exact path of k_hashfilter_ac
+#endif
 #ifdef RAISR_HIP_DEV
 #include "kernels_experiments.h"     // persistent-grid variant of k_hashfilter_ac (-DRAISR_EXP_PERSIST)
 #endif
+#ifdef RAISR_HIP_TESTHOOKS
 #include "kernels_split.h"           // k_hash_ac, k_fix_*, k_filter_lds16
+#endif
 #ifdef RAISR_HIP_DEV                 /* development builds only: measured slower than the exact path (docs/EXPERIMENTS.md) */
 #include "kernels_fast.h"            // k_filter_mfma
 #endif
@@ -233,14 +250,18 @@ struct raisr_hip_ctx {
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool defer = false;                        // RAISR_HIP_DEFER=1: uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist
                                                // (bit-exact; measured slower on every configuration, docs/EXPERIMENTS.md: k_fix_ac costs more than the main kernel gains)
+#ifdef RAISR_HIP_TESTHOOKS
     FixAc fixac{};                             // ... the list (sized at configure: tiles of the largest pass x batch depth)
+#endif
     bool split = false;                        // certified hash stage and filter stage as separate launches (RAISR_HIP_SPLIT=1)
     int fast = 0;                              // NON-bit-exact fast mode (raisr_hip_set_fast / RAISR_HIP_FAST): 1 = exact buckets, filter stage on the matrix cores; 2 = also keeps the approximate tensor's bucket where it is not certified
     bool lds_filter = true;                    // split pipeline: filter stage with the bank in LDS (RAISR_HIP_LDS_FILTER=0: k_filter)
     int n_cus = 256;                           // persistent k_filter_lds16 grid: one workgroup per CU (multiple of 4)
     float* d_gauss = nullptr;                  // GaussW::wT on the device (16-lane exact tensor of the worklist)
+#ifdef RAISR_HIP_TESTHOOKS
     FixLists fix{};                            // split pipeline: worklists of the certified hash stage (sized at configure)
     size_t fix_tiles = 0;
+#endif
     int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
     unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
     SepW sep{};
@@ -417,6 +438,7 @@ template <typename TOut>
 void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void* lrp, const PassParams& P, dim3 grid, bool sym, dim3 plane_tiles)
 {
     int slot;
+#ifdef RAISR_HIP_TESTHOOKS
     if (c->defer && !P.cert_check) {
         FixAc F = c->fixac;
         F.tiles_x = (int)plane_tiles.x;
@@ -431,6 +453,7 @@ void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void*
         timer_end(c, s, slot);
         return;
     }
+#endif
     timer_begin(c, "k_hashfilter_ac", s, slot);
     if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
     else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
@@ -468,6 +491,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         // a free treatment of those rows would be worth (docs/EXPERIMENTS.md)
         if (getenv("RAISR_HIP_SYM_IGNORE_ASYM")) { sym = true; P.asym = nullptr; }
 #endif
+#ifdef RAISR_HIP_TESTHOOKS
         if (c->fast || (c->fused && c->certify && c->split)) {
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
@@ -527,7 +551,9 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 hipLaunchKernelGGL((k_filter<TOut>), gf, dim3(256), 0, s, (const TOut*)lrp, (const uint8_t*)c->d_hash[pass], P, c->d_hr[pass], F.counters);
                 timer_end(c, s, slot);
             }
-        } else if (c->fused && c->certify && nchunks > 1 && !P.randomness && (int)gf.y >= 2 * nchunks) {
+        } else
+#endif
+        if (c->fused && c->certify && nchunks > 1 && !P.randomness && (int)gf.y >= 2 * nchunks) {
             P.write_hash = c->keep_hash_plane;
             P.cert_stats = c->d_cert_stats;
             P.cert_check = c->cert_check;
@@ -667,6 +693,7 @@ void free_scratch(raisr_hip_ctx* c)
     }
     if (c->d_mid) (void)hipFree(c->d_mid);
     c->d_mid = nullptr;
+#ifdef RAISR_HIP_TESTHOOKS
     if (c->fix.counters) (void)hipFree(c->fix.counters);
     if (c->fix.counts) (void)hipFree(c->fix.counts);
     if (c->fix.sparse) (void)hipFree(c->fix.sparse);
@@ -677,6 +704,7 @@ void free_scratch(raisr_hip_ctx* c)
     c->fixac = FixAc{};
     c->fix = FixLists{};
     c->fix_tiles = 0;
+#endif
 }
 
 }  // namespace
@@ -761,7 +789,12 @@ static int create_impl(raisr_hip_ctx* c)
 {
     if (const char* e = getenv("RAISR_HIP_FUSED")) c->fused = atoi(e) != 0;       // A/B switch: 0 = separate k_hash + k_filter
     if (const char* e = getenv("RAISR_HIP_CERTIFY")) c->certify = atoi(e) != 0;   // A/B switch: 0 = exact tensor for every pixel
-    if (const char* e = getenv("RAISR_HIP_DEFER")) c->defer = atoi(e) != 0;       // A/B switch: 1 = k_fix_ac instead of the in-tile worklist
+#ifdef RAISR_HIP_TESTHOOKS
+    if (const char* e = getenv("RAISR_HIP_DEFER")) c->defer = atoi(e) != 0;       // comparison pipeline: 1 = k_fix_ac instead of the in-tile worklist
+#else
+    for (const char* v : {"RAISR_HIP_DEFER", "RAISR_HIP_SPLIT"})                  // asked for, not in the product library: say so
+        if (const char* e = getenv(v)) if (atoi(e) > 0) return fail(RAISR_HIP_EINVAL, "RAISR_HIP_DEFER / RAISR_HIP_SPLIT select comparison pipelines that exist in builds with -DRAISR_HIP_TESTHOOKS only (libraisr_hip_testhooks.so)");
+#endif
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
@@ -770,7 +803,9 @@ static int create_impl(raisr_hip_ctx* c)
 #else
     if (const char* e = getenv("RAISR_HIP_FAST")) if (atoi(e) > 0) return fail(RAISR_HIP_EINVAL, kNoFastMode);           // asked for, not available: say so
 #endif
-    if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // A/B switch: 1 = k_hash_ac + filter kernel
+#ifdef RAISR_HIP_TESTHOOKS
+    if (const char* e = getenv("RAISR_HIP_SPLIT")) c->split = atoi(e) != 0;       // comparison pipeline: 1 = k_hash_ac + filter kernel
+#endif
     if (const char* e = getenv("RAISR_HIP_LDS_FILTER")) c->lds_filter = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_CHUNKS")) { const int v = atoi(e); c->chunks = v < 1 ? 1 : (v > 8 ? 8 : v); }
     {
@@ -785,10 +820,12 @@ static int create_impl(raisr_hip_ctx* c)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_mfma<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLds);
 #endif
+#ifdef RAISR_HIP_TESTHOOKS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_lds16<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+#endif
     }
     HIP_TRY(hipMalloc((void**)&c->d_gauss, sizeof(GaussW)));
     int rc = pool_get_stream(c->device, &c->stream);
@@ -1249,6 +1286,7 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
             return fail(RAISR_HIP_ENOMEM, "scratch plane alloc");
         }
     }
+#ifdef RAISR_HIP_TESTHOOKS
     if (cfg->hash_variant != RAISR_HIP_HASH_FP16) {   // worklists of the split pipeline (largest pass geometry)
         size_t tiles = 0;
         for (int p = 0; p < cfg->passes; p++) {
@@ -1272,6 +1310,7 @@ int raisr_hip_configure(raisr_hip_ctx* c, const raisr_hip_config* cfg)
         }
         HIP_TRY(hipMemsetAsync(c->fixac.counts, 0, cap * tiles * 4, c->stream));
     }
+#endif
     if (cfg->passes == 2) {
         // pixels the Randomness pass never writes stay 0 in the intermediate (the reference leaves heap garbage there)
         HIP_TRY(hipMemsetAsync(c->d_lr[1], 0, cap * (size_t)c->passW[1] * c->passH[1] * bps, c->stream));
@@ -1825,6 +1864,7 @@ int raisr_hip_packed_frame_layout(int y_w, int y_h, int c_w, int c_h, int bits, 
     return RAISR_HIP_OK;
 }
 
+#ifdef RAISR_HIP_TESTHOOKS        /* ---- include/raisr_hip_debug.h: not in the product library ---- */
 int raisr_hip_debug_keep_stages(raisr_hip_ctx* c, int on)
 {
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
@@ -1957,6 +1997,8 @@ int raisr_hip_debug_hash(raisr_hip_ctx* c, int pass_index, int hash_flavour, con
     return rc;
 }
 
+#endif  /* RAISR_HIP_TESTHOOKS */
+
 // Enable/disable per-kernel HIP-event timing of subsequent process calls (events are recorded on the
 // stream each kernel is launched on).
 int raisr_hip_kernel_timing_enable(raisr_hip_ctx* c, int on)
@@ -1992,6 +2034,7 @@ int raisr_hip_kernel_timing_read(raisr_hip_ctx* c, char* names_out, float* total
     return n;
 }
 
+#ifdef RAISR_HIP_TESTHOOKS
 int raisr_hip_profile_kernels(raisr_hip_ctx* c, const void* d_in, size_t in_pitch, void* d_out, size_t out_pitch,
                               int iters, char* names_out, float* ms_out, int max_kernels)
 {
@@ -2010,6 +2053,8 @@ int raisr_hip_profile_kernels(raisr_hip_ctx* c, const void* d_in, size_t in_pitc
     raisr_hip_kernel_timing_enable(c, 0);
     return n;
 }
+
+#endif  /* RAISR_HIP_TESTHOOKS */
 
 }  // extern "C"
 

@@ -116,10 +116,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off[ch]);
         if (SYM) tap[4] = l >= 9 ? reinterpret_cast<const char*>(zpad) : tap[4];
         const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
-#if defined(RAISR_HIP_DEV) && defined(RAISR_EXP_NO_WINDOW)
-        // TIMING PROBE, output wrong: every step reads step 0's window values, so the compiler keeps them in registers: eight LDS
-        // reads per row instead of 128
-#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p)))
+#ifdef RAISR_PROBE_LDS_F                                         /* development builds: timing probe from kernels_probes.h */
+#define RAISR_LDS_F(p, s) RAISR_PROBE_LDS_F(p, s)
 #else
 #define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
 #endif
@@ -190,24 +188,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
                 for (int ch = 0; ch < 4; ch++) q[4 + ch] = __uint_as_float(fb[ch]);
             }
         };
-#if defined(RAISR_HIP_DEV) && (defined(RAISR_EXP_COEF_REUSE) || defined(RAISR_EXP_NO_WINDOW))
-        // TIMING PROBES, output wrong (docs/EXPERIMENTS.md I.4), on the compiler's own schedule.  RAISR_EXP_COEF_REUSE = n: coefficients
-        // are fetched for every n-th step only and reused for the steps between -- what any scheme that shares coefficient rows
-        // between pixels (key-chunked stage) could gain at most, with its sort, scattered window reads and scattered stores for free.
-#ifndef RAISR_EXP_COEF_REUSE
-#define RAISR_EXP_COEF_REUSE 1
-#endif
-        {
-            float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 16; s++) {
-                if (s % RAISR_EXP_COEF_REUSE == 0) load_q(sH[prow * TW + 4 * s + g], qr);
-                float x[8];
-#pragma unroll
-                for (int ch = 0; ch < 8; ch++) x[ch] = RAISR_LDS_F(tap[ch], s);
-                A16[s] = chain(x, qr);
-            }
-        }
+#ifdef RAISR_PROBE_FILTER_STEPS                                  /* development builds: timing probe from kernels_probes.h (output wrong) */
+        RAISR_PROBE_FILTER_STEPS
 #else
         {
             // The steps, software-pipelined by hand in pairs (a ds_read2_b32 fetches one tap of two steps): the coefficient loads and

@@ -20,7 +20,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAISR_HIP_LIB: an experimental build of the same library (scripts/build_exp.sh) for A/B runs on one GPU box; never a fallback
 _SO = os.environ.get("RAISR_HIP_LIB") or os.path.join(_HERE, "libraisr_hip.so")
+# the same sources with -DRAISR_HIP_TESTHOOKS: the product library plus the raisr_hip_debug_* entry points (include/raisr_hip_debug.h)
+# and the selectable pipelines that exist for comparisons only (RAISR_HIP_SPLIT, RAISR_HIP_DEFER).  Tests and bench.py's self-check
+# legs load it through RaisrDevice(..., hooks=True); the product library does not carry any of it.
+_SO_HOOKS = os.environ.get("RAISR_HIP_LIB") or os.path.join(_HERE, "libraisr_hip_testhooks.so")
 _LIB = None
+_LIB_HOOKS = None
 
 # RaisrDefaults.h enums
 RNLErrorNone = 0
@@ -58,16 +63,15 @@ class RaisrHipConfig(ctypes.Structure):
 
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO_HOOKS):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libraisr_hip.so", "libraisr_hip_testhooks.so"] + (["-B"] if force else []))
     return _SO
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(_SO):
-            raise RuntimeError(f"{_SO} is missing: build it with `make -C {_HERE}` (hipcc, gfx950). "
+def _load(path):
+    if True:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C {_HERE}` (hipcc, gfx950). "
                                "There is no CPU fallback.")
         # libraisr_hip.so and PyTorch-ROCm both need "libamdhip64.so.7"; the dynamic loader keeps one
         # copy per SONAME, so whichever is loaded first serves both.  PyTorch only works on its own
@@ -77,7 +81,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = ctypes.CDLL(_SO)
+        L = ctypes.CDLL(path)
         L.raisr_hip_last_error.restype = ctypes.c_char_p
         L.raisr_hip_version.restype = ctypes.c_char_p
         L.raisr_hip_model_blob_bytes.restype = ctypes.c_size_t
@@ -104,10 +108,13 @@ def lib():
         L.raisr_hip_process_host.argtypes = ([ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_size_t] * 6 + [ctypes.c_int] * 4)
         L.raisr_hip_synchronize.argtypes = [ctypes.c_void_p]
         L.raisr_hip_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        L.raisr_hip_debug_keep_stages.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        if hasattr(L, "raisr_hip_debug_keep_stages"):
+            L.raisr_hip_debug_keep_stages.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        if hasattr(L, "raisr_hip_debug_read_stage"):
+            L.raisr_hip_debug_read_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_plan_bands.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RaisrHipBand)]
-        L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        if hasattr(L, "raisr_hip_debug_hash"):
+            L.raisr_hip_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
         if os.environ.get("RAISR_HIP_LIB") is None or hasattr(L, "raisr_hip_stream_create_multi"):     # (an older A/B build may lack the multi-device ring)
             L.raisr_hip_stream_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -142,16 +149,19 @@ def lib():
         L.RNLHandler_HostFree.argtypes = [ctypes.c_void_p]
         L.RNLHandler_HostFree.restype = None
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
-        L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
-                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        if os.environ.get("RAISR_HIP_LIB") is None or hasattr(L, "raisr_hip_debug_fold16_check"):      # (an older A/B build may lack the newest hooks)
+        if hasattr(L, "raisr_hip_debug_approx_hash"):
+            L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        if hasattr(L, "raisr_hip_debug_fold16_check"):
             L.raisr_hip_debug_fold16_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        if hasattr(L, "raisr_hip_debug_certify"):
+            L.raisr_hip_debug_certify.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.raisr_hip_set_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_use_streams.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_broadcast_model_blob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.raisr_hip_get_fast.argtypes = [ctypes.c_void_p]
-        L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if hasattr(L, "raisr_hip_debug_certify_stats"):
+            L.raisr_hip_debug_certify_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.raisr_hip_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.raisr_hip_kernel_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.RNLHandler_Init.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
@@ -163,8 +173,25 @@ def lib():
         L.RNLHandler_SetAsyncDepth.argtypes = [ctypes.c_uint]
         L.raisr_hip_stream_set_blending.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.RNLHandler_SetOpenCLContext.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        _LIB = L
+        return L
+
+
+
+
+def lib():
+    """The product library."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _load(_SO)
     return _LIB
+
+
+def lib_hooks():
+    """The test-hooks flavour (raisr_hip_debug_*, comparison pipelines)."""
+    global _LIB_HOOKS
+    if _LIB_HOOKS is None:
+        _LIB_HOOKS = lib() if _SO_HOOKS == _SO else _load(_SO_HOOKS)
+    return _LIB_HOOKS
 
 
 def last_error():
@@ -353,14 +380,27 @@ def pack_model_blob(bank, qstr, qcoh, quant_angle):
 class RaisrDevice:
     """One in-flight-frame lane of the device-resident hot path."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, hooks=False):
+        """hooks=True: a context of the test-hooks flavour (libraisr_hip_testhooks.so): the debug_* / certify_* / keep_stages methods and the
+        comparison pipelines (RAISR_HIP_SPLIT, RAISR_HIP_DEFER) exist there only."""
+        self._L = lib_hooks() if hooks else lib()
         self._h = ctypes.c_void_p()
-        _check(lib().raisr_hip_create(ctypes.byref(self._h), device), "raisr_hip_create")
+        self._check(self._L.raisr_hip_create(ctypes.byref(self._h), device), "raisr_hip_create")
         self.cfg = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._L.raisr_hip_last_error().decode()}")
+
+    def _hook(self, name):
+        f = getattr(self._L, name, None)
+        if f is None:
+            raise RuntimeError(f"{name} is not part of the product library: create the device with hooks=True (libraisr_hip_testhooks.so)")
+        return f
 
     def close(self):
         if self._h:
-            lib().raisr_hip_destroy(self._h)
+            self._L.raisr_hip_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -378,11 +418,11 @@ class RaisrDevice:
         bank = np.ascontiguousarray(bank, np.float32)
         qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
         hk, pt, _ = bank.shape
-        _check(lib().raisr_hip_set_model(self._h, pass_index, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
+        self._check(self._L.raisr_hip_set_model(self._h, pass_index, bank.ctypes.data, hk, pt, qstr.ctypes.data, qcoh.ctypes.data,
                                          quant_angle), "raisr_hip_set_model")
 
     def set_model_blob_device(self, pass_index, dev_ptr, nbytes, stream=None):
-        _check(lib().raisr_hip_set_model_blob_device(self._h, pass_index, dev_ptr, nbytes, stream), "set_model_blob_device")
+        self._check(self._L.raisr_hip_set_model_blob_device(self._h, pass_index, dev_ptr, nbytes, stream), "set_model_blob_device")
 
     def configure(self, in_w, in_h, out_w, out_h, bits=8, full_range=False, passes=1, mode=1, hash_variant=HASH_AVX512,
                   blending=BLEND_COUNT, ratio2=None, tie=TIE_HALF_UP):
@@ -394,11 +434,11 @@ class RaisrDevice:
         c.hash_variant, c.blending = hash_variant, blending
         c.use_pixel_type = int(out_w == 2 * in_w and out_h == 2 * in_h) if ratio2 is None else int(ratio2)
         c.tie_rule = tie
-        _check(lib().raisr_hip_configure(self._h, ctypes.byref(c)), "raisr_hip_configure")
+        self._check(self._L.raisr_hip_configure(self._h, ctypes.byref(c)), "raisr_hip_configure")
         self.cfg = c
 
     def process_y(self, d_in, in_pitch, d_out, out_pitch, stream=None):
-        _check(lib().raisr_hip_process_y_device(self._h, d_in, in_pitch, d_out, out_pitch, stream), "raisr_hip_process_y_device")
+        self._check(self._L.raisr_hip_process_y_device(self._h, d_in, in_pitch, d_out, out_pitch, stream), "raisr_hip_process_y_device")
 
     def process_y_batch(self, d_in_list, in_pitch, d_out_list, out_pitch, stream=None):
         """n device-resident frames through one launch per kernel (equally spaced planes; otherwise frame by frame)"""
@@ -408,14 +448,14 @@ class RaisrDevice:
         if key not in cache:                                   # pointer tables are reused by loops that resubmit the same planes
             cache[key] = ((ctypes.c_void_p * n)(*d_in_list), (ctypes.c_void_p * n)(*d_out_list))
         a_in, a_out = cache[key]
-        _check(lib().raisr_hip_process_y_device_batch(self._h, n, a_in, in_pitch, a_out, out_pitch, stream), "raisr_hip_process_y_device_batch")
+        self._check(self._L.raisr_hip_process_y_device_batch(self._h, n, a_in, in_pitch, a_out, out_pitch, stream), "raisr_hip_process_y_device_batch")
 
     def resize_plane(self, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream=None):
-        _check(lib().raisr_hip_resize_plane_device(self._h, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream),
+        self._check(self._L.raisr_hip_resize_plane_device(self._h, d_src, sw, sh, spitch, d_dst, dw, dh, dpitch, bits, stream),
                "raisr_hip_resize_plane_device")
 
     def process_frame(self, d_y, y_pitch, d_oy, oy_pitch, d_u, d_v, c_pitch, d_ou, d_ov, oc_pitch, cw, ch, ocw, och, stream=None):
-        _check(lib().raisr_hip_process_frame_device(self._h, d_y, y_pitch, d_oy, oy_pitch, d_u, d_v, c_pitch, d_ou, d_ov, oc_pitch,
+        self._check(self._L.raisr_hip_process_frame_device(self._h, d_y, y_pitch, d_oy, oy_pitch, d_u, d_v, c_pitch, d_ou, d_ov, oc_pitch,
                                                     cw, ch, ocw, och, stream), "raisr_hip_process_frame_device")
 
     def process_host(self, y, oy, u=None, ou=None, v=None, ov=None):
@@ -424,36 +464,36 @@ class RaisrDevice:
         args = [*pp(y), *pp(oy), *pp(u), *pp(ou), *pp(v), *pp(ov)]
         cw, ch = (u.shape[1], u.shape[0]) if u is not None else (0, 0)
         ocw, och = (ou.shape[1], ou.shape[0]) if ou is not None else (0, 0)
-        _check(lib().raisr_hip_process_host(self._h, *args, cw, ch, ocw, och), "raisr_hip_process_host")
+        self._check(self._L.raisr_hip_process_host(self._h, *args, cw, ch, ocw, och), "raisr_hip_process_host")
 
     def set_blending(self, blending):
-        _check(lib().raisr_hip_set_blending(self._h, blending), "raisr_hip_set_blending")
+        self._check(self._L.raisr_hip_set_blending(self._h, blending), "raisr_hip_set_blending")
 
     def synchronize(self):
-        _check(lib().raisr_hip_synchronize(self._h), "raisr_hip_synchronize")
+        self._check(self._L.raisr_hip_synchronize(self._h), "raisr_hip_synchronize")
 
     def keep_stages(self, on=True):
-        _check(lib().raisr_hip_debug_keep_stages(self._h, int(on)), "debug_keep_stages")
+        self._check(self._hook("raisr_hip_debug_keep_stages")(self._h, int(on)), "debug_keep_stages")
 
     def read_stage(self, pass_index=0):
         mode2 = self.cfg.passes == 2 and self.cfg.two_pass_mode == 2
         w = self.cfg.in_width if (pass_index == 0 and mode2) else self.cfg.out_width
         h = self.cfg.in_height if (pass_index == 0 and mode2) else self.cfg.out_height
         hs = np.zeros((h, w), np.uint8); hr = np.zeros((h, w), np.float32)
-        _check(lib().raisr_hip_debug_read_stage(self._h, pass_index, hs.ctypes.data, hr.ctypes.data), "debug_read_stage")
+        self._check(self._hook("raisr_hip_debug_read_stage")(self._h, pass_index, hs.ctypes.data, hr.ctypes.data), "debug_read_stage")
         return hs, hr
 
     def debug_hash(self, abd, pass_index=0, flavour=HASH_AVX512):
         """Hash buckets of an (n, 3) float32 array of structure-tensor triples, via the device hash functions."""
         abd = np.ascontiguousarray(abd, np.float32)
         out = np.zeros(abd.shape[0], np.uint8)
-        _check(lib().raisr_hip_debug_hash(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
+        self._check(self._hook("raisr_hip_debug_hash")(self._h, pass_index, flavour, abd.ctypes.data, abd.shape[0], out.ctypes.data), "debug_hash")
         return out
 
     def debug_fold16_check(self, pass_index=0):
         """(disagreements, pairs compared) of the binary16 hash's folded thresholds vs the divisions, exhaustive on the device"""
         out = (ctypes.c_ulonglong * 2)()
-        _check(lib().raisr_hip_debug_fold16_check(self._h, pass_index, out), "debug_fold16_check")
+        self._check(self._hook("raisr_hip_debug_fold16_check")(self._h, pass_index, out), "debug_fold16_check")
         return int(out[0]), int(out[1])
 
     def debug_approx_hash(self, abd, pass_index=0, flavour=HASH_AVX512):
@@ -461,39 +501,39 @@ class RaisrDevice:
         abd = np.ascontiguousarray(abd, np.float32)
         n = abd.shape[0]
         bucket = np.zeros(n, np.uint8); cert = np.zeros(n, np.uint8); eps = ctypes.c_float()
-        _check(lib().raisr_hip_debug_approx_hash(self._h, pass_index, flavour, abd.ctypes.data, n, bucket.ctypes.data, cert.ctypes.data,
+        self._check(self._hook("raisr_hip_debug_approx_hash")(self._h, pass_index, flavour, abd.ctypes.data, n, bucket.ctypes.data, cert.ctypes.data,
                                                  ctypes.byref(eps)), "debug_approx_hash")
         return bucket, cert.astype(bool), float(eps.value)
 
     def use_streams(self, compute=None, upload=None, download=None):
         """Run the host-plane entry points on caller-owned hipStream_t handles (all three or none; None restores the context's own)."""
-        _check(lib().raisr_hip_use_streams(self._h, compute, upload, download), "raisr_hip_use_streams")
+        self._check(self._L.raisr_hip_use_streams(self._h, compute, upload, download), "raisr_hip_use_streams")
 
     def set_fast(self, on=1):
         """NON-bit-exact fast mode. 1: exact buckets, filter stage on the matrix cores (binary16 coefficients);
         2: also keeps the approximate tensor's bucket where the hash stage cannot certify it (no exact re-hash)."""
-        _check(lib().raisr_hip_set_fast(self._h, int(on)), "set_fast")
+        self._check(self._L.raisr_hip_set_fast(self._h, int(on)), "set_fast")
 
     def fast(self):
-        return int(lib().raisr_hip_get_fast(self._h))
+        return int(self._L.raisr_hip_get_fast(self._h))
 
     def certify_debug(self, collect=True, check=False):
         """Certified hash stage: start (and zero) / stop the statistics; check=True also runs the exact path for every pixel."""
-        _check(lib().raisr_hip_debug_certify(self._h, int(collect), int(check)), "debug_certify")
+        self._check(self._hook("raisr_hip_debug_certify")(self._h, int(collect), int(check)), "debug_certify")
 
     def certify_stats(self):
         """dict(uncertain, mismatches, pixels) accumulated since certify_debug(True, ...)."""
         out = (ctypes.c_uint * 3)()
-        _check(lib().raisr_hip_debug_certify_stats(self._h, out), "debug_certify_stats")
+        self._check(self._hook("raisr_hip_debug_certify_stats")(self._h, out), "debug_certify_stats")
         return {"uncertain": int(out[0]), "mismatches": int(out[1]), "pixels": int(out[2])}
 
     def timing_enable(self, on=True):
-        _check(lib().raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
+        self._check(self._L.raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
 
     def timing_read(self, max_kernels=16):
         names = ctypes.create_string_buffer(64 * max_kernels)
         ms = (ctypes.c_float * max_kernels)(); cnt = (ctypes.c_int * max_kernels)()
-        n = lib().raisr_hip_kernel_timing_read(self._h, names, ms, cnt, max_kernels)
+        n = self._L.raisr_hip_kernel_timing_read(self._h, names, ms, cnt, max_kernels)
         if n < 0:
             raise RuntimeError(last_error())
         out = {}
