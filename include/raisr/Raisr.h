@@ -55,6 +55,7 @@ RNLERRORTYPE RNLDeinit();
 
 /* Asynchronous frames (extension, see RaisrHandler.h): up to `depth` frames in flight. */
 RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth);
+int RNLAsyncCapacity();
 RNLERRORTYPE RNLSetDeviceList(const char *devices);     /* "0,1,2" | "all" | "": GPUs of the asynchronous ring (RaisrHandler.h) */
 RNLERRORTYPE RNLSubmit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
                        VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb,

@@ -66,6 +66,7 @@ RNLERRORTYPE RNLHandler_Deinit(void);
  */
 RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth);
 RNLERRORTYPE RNLHandler_SetDeviceList(const char *devices);
+int RNLHandler_AsyncCapacity(void);        /* frames Submit accepts before a Collect is due: depth x the GPUs of the device list (0: no ring asked for) */
 RNLERRORTYPE RNLHandler_Submit(VideoDataType *srcY, VideoDataType *srcCr, VideoDataType *srcCb,
                                VideoDataType *dstY, VideoDataType *dstCr, VideoDataType *dstCb,
                                BlendingMode blend);

@@ -39,6 +39,9 @@ def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_pat
     for needle in ('{"async",', "RNLHandler_SetAsyncDepth(raisr->async)", "RNLHandler_Submit(", "RNLHandler_Collect()",
                    ".request_frame = request_frame", "ret == AVERROR_EOF && raisr->q_count > 0", "collect_oldest(ctx, 0)"):
         assert needle in src, needle
+    # devices=0,1,..|all: the ring spans several GPUs, the filter keeps async frames in flight on each
+    for needle in ('{"devices",', "RNLHandler_SetDeviceList(raisr->devices)", "RNLHandler_AsyncCapacity()", "raisr->q_count == raisr->q_cap"):
+        assert needle in src, needle
     # pinned=1: input and output frames from buffer pools over the library's page-locked allocator (the buffer owns the memory:
     # nothing is page-locked behind FFmpeg's back, nothing outlives its buffer)
     for needle in ('{"pinned",', "RNLHandler_HostAlloc(size)", "RNLHandler_HostFree(data)", "av_buffer_pool_init2(size + 4 * 64 /* tail padding",

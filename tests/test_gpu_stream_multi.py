@@ -111,6 +111,7 @@ def test_plugin_api_ring_over_a_device_list(how, monkeypatch):
         if how == "call":
             assert R.RNLHandler_SetDeviceList("0,0") == 0
         assert R.RNLHandler_SetAsyncDepth(2) == 0
+        assert R.RNLHandler_AsyncCapacity() == 4                                                  # before the ring exists: depth x listed GPUs
         inflight = done = 0
         for i in range(n):
             if inflight == 4:                                                                     # 2 device slots x depth 2

@@ -686,6 +686,30 @@ RNLERRORTYPE RNLSetDeviceList(const char *devices)
     return RNLErrorNone;
 }
 
+// the ring's GPUs: RNLSetDeviceList, else RAISR_HIP_DEVICES, else the handler's one device; false: RAISR_HIP_DEVICES is malformed
+static bool ringDevices(std::vector<int> &devs)
+{
+    devs = G.devices;
+    if (devs.empty()) {
+        if (const char *e = std::getenv("RAISR_HIP_DEVICES")) {
+            int list[RAISR_HIP_STREAM_MAX_DEVICES];
+            const int n = raisr_hip_parse_device_list(e, list, RAISR_HIP_STREAM_MAX_DEVICES);
+            if (n < 0) { std::cout << "[RAISR ERROR] RAISR_HIP_DEVICES=" << e << ": not a list of HIP devices of this machine" << std::endl; return false; }
+            devs.assign(list, list + n);
+        }
+    }
+    if (devs.empty()) devs.push_back(G.device);
+    return true;
+}
+
+int RNLAsyncCapacity()
+{
+    if (G.ring) return raisr_hip_stream_depth(G.ring);
+    std::vector<int> devs;
+    if (G.asyncDepth == 0 || !ringDevices(devs)) return 0;
+    return (int)(devs.size() * G.asyncDepth);
+}
+
 static RNLERRORTYPE checkFrame(VideoDataType *const pl[6])
 {
     for (int i = 0; i < 6; i++) if (!pl[i] || !pl[i]->pData) return RNLErrorBadParameter;
@@ -714,17 +738,8 @@ RNLERRORTYPE RNLSubmit(VideoDataType *inY, VideoDataType *inCr, VideoDataType *i
         return RNLErrorUndefined;
     };
     if (!G.ring) {
-        // the ring's GPUs: RNLSetDeviceList, else RAISR_HIP_DEVICES, else the handler's one device
-        std::vector<int> devs = G.devices;
-        if (devs.empty()) {
-            if (const char *e = std::getenv("RAISR_HIP_DEVICES")) {
-                int list[RAISR_HIP_STREAM_MAX_DEVICES];
-                const int n = raisr_hip_parse_device_list(e, list, RAISR_HIP_STREAM_MAX_DEVICES);
-                if (n < 0) { std::cout << "[RAISR ERROR] RAISR_HIP_DEVICES=" << e << ": not a list of HIP devices of this machine" << std::endl; return RNLErrorBadParameter; }
-                devs.assign(list, list + n);
-            }
-        }
-        if (devs.empty()) devs.push_back(G.device);
+        std::vector<int> devs;
+        if (!ringDevices(devs)) return RNLErrorBadParameter;
         int rc = raisr_hip_stream_create_multi(&G.ring, devs.data(), (int)devs.size(), (int)G.asyncDepth);
         if (rc != RAISR_HIP_OK) { G.ring = nullptr; return rc == RAISR_HIP_ENOMEM ? RNLErrorInsufficientResources : failed("async ring"); }
         for (unsigned p = 0; p < G.passes && rc == RAISR_HIP_OK; p++) {
@@ -792,6 +807,7 @@ RNLERRORTYPE RNLHandler_Deinit(void)
 
 RNLERRORTYPE RNLHandler_SetAsyncDepth(unsigned int depth) { return RNLSetAsyncDepth(depth); }
 RNLERRORTYPE RNLHandler_SetDeviceList(const char *devices) { return RNLSetDeviceList(devices); }
+int RNLHandler_AsyncCapacity(void) { return RNLAsyncCapacity(); }
 
 RNLERRORTYPE RNLHandler_Submit(VideoDataType *inY, VideoDataType *inU, VideoDataType *inV,
                                VideoDataType *outY, VideoDataType *outU, VideoDataType *outV, BlendingMode blendingMode)

@@ -243,6 +243,11 @@ def RNLHandler_SetAsyncDepth(depth):
     return int(lib().RNLHandler_SetAsyncDepth(ctypes.c_uint(depth)))
 
 
+def RNLHandler_AsyncCapacity():
+    """Frames Submit accepts before a Collect is due: depth x the GPUs of the device list."""
+    return lib().RNLHandler_AsyncCapacity()
+
+
 def RNLHandler_SetDeviceList(devices):
     """GPUs of the asynchronous ring: "0,1,2" | "all" | "" (RaisrHandler.h)."""
     return lib().RNLHandler_SetDeviceList(devices.encode() if isinstance(devices, str) else devices)
