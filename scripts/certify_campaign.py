@@ -2,7 +2,10 @@
 path; a certified bucket that differs from the exact one is counted (must stay 0).
 Round 3 matrix: 8-bit 2x (three models, both hash flavours, 2-pass mode 1 -- the round-2 campaign), plus 10-bit 2x, 16-bit 2x
 (synthesised `_16` folder), 1.5x (one pixel type) and 2-pass mode 2 (pass 1 at input size), each on natural / noise /
-smooth-gradient-with-edges frames.  Usage: certify_campaign.py [frames per kind] -> gpurun_out/certify_campaign.json"""
+smooth-gradient-with-edges frames.  Round 5 (KINDS=r05): three more frame families on the same matrix -- ramps (linear gradients of
+integer and fractional slope in every orientation, piecewise: long runs of identical windows, exact symmetries), text-like edges
+(two-level glyph strokes 1-3 px wide on flat or gently shaded ground) and film grain (natural frames + Gaussian grain).
+Usage: [KINDS=r05] certify_campaign.py [frames per kind] -> gpurun_out/certify_campaign.json"""
 import json, os, shutil, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +50,39 @@ def frames(i, w, h, bits):
     g = g * maxv
     g[(xx * np.cos(ph[3]) + yy * np.sin(ph[3])) % 97 < 3] = hi
     smooth = np.clip(g + rng.integers(-1, 2, g.shape) * max(1, maxv // 255), lo, hi).astype(nat.dtype)
-    return [nat, rnd, smooth]
+    if os.environ.get("KINDS") != "r05":
+        return [nat, rnd, smooth]
+    # ramps: piecewise linear gradients, slopes from 1/16 to 4 levels per pixel (scaled to the bit depth), random orientation per band
+    sc = max(1, maxv // 255)
+    ramp = np.zeros((h, w), np.float64)
+    band = max(32, h // 12)
+    for b0 in range(0, h, band):
+        th = rng.uniform(0, np.pi)
+        sl = rng.choice([1 / 16, 1 / 4, 1 / 2, 1, 2, 4]) * sc
+        ramp[b0:b0 + band] = (lo + (sl * (xx[b0:b0 + band] * np.cos(th) + yy[b0:b0 + band] * np.sin(th))) % (hi - lo))
+    ramp = np.floor(ramp).clip(lo, hi).astype(nat.dtype)
+    # text-like: strokes (horizontal, vertical, diagonal) 1-3 px wide, dark on light or light on dark, on a flat or faintly shaded ground
+    ground = (lo + (hi - lo) * (0.75 + 0.05 * np.sin(0.003 * xx + ph[0]))).astype(np.float64)
+    ink = float(lo + (hi - lo) * 0.08)
+    txt = ground.copy()
+    for _ in range(w * h // 900):
+        x0, y0 = int(rng.integers(0, w - 24)), int(rng.integers(0, h - 24))
+        ln, wd, kind = int(rng.integers(5, 22)), int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        if kind == 0:
+            txt[y0:y0 + wd, x0:x0 + ln] = ink
+        elif kind == 1:
+            txt[y0:y0 + ln, x0:x0 + wd] = ink
+        else:
+            for t in range(ln):
+                xx0 = x0 + t if kind == 2 else x0 + ln - t
+                txt[y0 + t:y0 + t + wd, xx0:xx0 + wd] = ink
+    if i & 1:
+        txt = lo + hi - txt                                   # light on dark
+    txt = txt.clip(lo, hi).astype(nat.dtype)
+    # film grain: the natural frame with Gaussian grain of sigma 1.5-6 levels (8-bit scale), brighter areas a little grainier
+    sig = rng.uniform(1.5, 6.0) * sc
+    grain = np.clip(nat.astype(np.float64) + rng.standard_normal((h, w)) * sig * (0.6 + 0.4 * nat / maxv), 0, maxv).astype(nat.dtype)
+    return [ramp, txt, grain]
 
 
 tot = {}
@@ -71,6 +106,6 @@ for key, fold, w, h, ow, oh, bits, passes, mode, asm, full, nn in MATRIX:
     assert st["mismatches"] == 0, (key, st)
 shutil.rmtree(tmp, ignore_errors=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump({"frames_per_kind": n, "kinds": ["natural", "noise", "smooth gradients with hard edges"],
+json.dump({"frames_per_kind": n, "kinds": ["ramps", "text-like edges", "film grain"] if os.environ.get("KINDS") == "r05" else ["natural", "noise", "smooth gradients with hard edges"],
            "buckets_compared": sum(v["pixels"] for v in tot.values()), "certified_but_wrong": sum(v["mismatches"] for v in tot.values()),
            "results": tot}, open(os.path.join(ROOT, "gpurun_out", "certify_campaign.json"), "w"), indent=1)
