@@ -156,3 +156,21 @@ def test_blob_broadcast_over_a_device_list_copies_the_blob():
     for d in dsts:
         assert torch.equal(d, src)
     assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 0, ptrs, blob.size) != 0
+
+
+def test_in_process_rccl_broadcast_with_one_rank(monkeypatch):
+    """The RCCL leg of raisr_hip_broadcast_model_blob_devices (ncclCommInitAll, grouped ncclBroadcast, ncclCommDestroy through the
+    dlopen'ed librccl) needs distinct devices; a one-GPU box can run it with ONE rank only (RAISR_HIP_FORCE_RCCL=1): the symbols
+    resolve, the communicator comes up and goes away, the root's blob is untouched."""
+    import raisr_hip as R
+    import torch
+    monkeypatch.setenv("RAISR_HIP_FORCE_RCCL", "1")
+    bank, qstr, qcoh, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, 1)
+    blob = R.pack_model_blob(bank, qstr, qcoh, qa)
+    src = torch.from_numpy(blob).cuda()
+    keep = src.clone()
+    devs = (ctypes.c_int * 1)(0)
+    ptrs = (ctypes.c_void_p * 1)(src.data_ptr())
+    assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 1, ptrs, blob.size) == 0, R.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(src, keep)
