@@ -155,3 +155,31 @@ def test_fp16_pipeline_on_10bit_content(passes, mode, full):
             dev.close()
         bad = np.argwhere(out != ref)
         assert bad.size == 0, (nm, len(bad), bad[:5].tolist())
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[4], CASES[6], CASES[7]], ids=lambda c: c[0])
+def test_letterboxed_and_flat_regions_bit_exact(case):
+    """Flat tiles (csrc/kernels_filter.h: not one non-zero gradient in the tile's 26 x 74 gradient tile) skip the hash stage and take the
+    zero tensor's bucket.  Letterbox bars, a flat rectangle inside the picture, a bar one sample off its neighbours (gradients only at
+    the seam), flat regions ending inside a tile and in the tail columns: every pixel must still equal the oracle's."""
+    import synth
+    bits = case[3]
+    dt = dtype_for(bits)
+    for (w, h) in ((416, 240), (134, 120)):
+        y = synth.natural_y(w, h, bits, seed=321).astype(dt)
+        top, bot = h // 5, h - h // 6
+        y[:top] = 16 << (bits - 8)                       # letterbox bars at the legal-range black level
+        y[bot:] = 16 << (bits - 8)
+        y[top + 20:top + 60, w // 4:w // 4 + 90] = 200 << (bits - 8)          # a flat rectangle inside the picture (hard edges around it)
+        y[bot - 30:bot - 10, :] = 90 << (bits - 8)                            # a full-width flat band ...
+        y[bot - 20, :] += 1                                                   # ... with a one-level seam through it
+        ref = _oracle(y, case)
+        got, _ = _gpu(y, case)
+        bad = np.argwhere(ref != got)
+        assert bad.size == 0, f"{case[0]} {w}x{h}: {len(bad)} mismatching pixels, first at {bad[:5].tolist()}"
+    # an all-black frame and a frame that is flat except for ONE sample
+    for (w, h) in ((200, 96),):
+        y = np.full((h, w), 16 << (bits - 8), dt)
+        assert np.array_equal(_oracle(y, case), _gpu(y, case)[0])
+        y[h // 2, w // 2] += 3
+        assert np.array_equal(_oracle(y, case), _gpu(y, case)[0])

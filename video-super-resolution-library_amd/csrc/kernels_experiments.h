@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256, RAISR_EXP_PERSIST_WGS) void k_hashfilter_acp(c
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];
     __shared__ uint16_t sList[kListMax];
-    __shared__ unsigned sCnt[3];
+    __shared__ unsigned sCnt[4];
     const unsigned ntiles = (unsigned)(tiles_x * tiles_y);
     if (skew_ticks > 0) {                                  // de-phase the workgroups that share a CU (k-th workgroup of a CU starts k * skew later)
         const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x / (unsigned)ncus) * (unsigned)skew_ticks);

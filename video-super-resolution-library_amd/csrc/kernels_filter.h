@@ -374,14 +374,16 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
 
     RAISR_PHASE_DECL;
-    if (!DEFER && tid < 3) sCnt[tid] = 0;
+    if (!DEFER && tid < 4) sCnt[tid] = 0;
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL, tid);
     __syncthreads();
     RAISR_PHASE(0);
+    unsigned any_grad = 0u;                                    // OR of the bit patterns of this thread's gradients (x - x is +0: all zero bits <=> flat)
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
         auto grad = [&](int ty, int tx) {
             const float gxv = sL[(ty + 2) * LW + tx + 1] - sL[ty * LW + tx + 1];
             const float gyv = sL[(ty + 1) * LW + tx + 2] - sL[(ty + 1) * LW + tx];
+            any_grad |= __float_as_uint(gxv) | __float_as_uint(gyv);      // one v_or3_b32
             grad_store(&sG[ty * GW_ + tx], gxv, gyv);
         };
         const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -397,8 +399,14 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
             if (idx < NR) grad(ty, tx);
         }
     }
+    if (!DEFER && __any(any_grad != 0u) && lane == 0) sCnt[3] = 1u;  // one LDS store per wave that saw a gradient
     __syncthreads();
     RAISR_PHASE(1);
+    // FLAT TILE: not one non-zero gradient in the whole 26 x 74 gradient tile -- letterbox bars, flat graphics, fades to black.  Every
+    // window of the tile is flat, so the reference's tensor is exactly (0, 0, 0) for every pixel (as in the per-pixel `zero` case of the
+    // hash stage) and the buckets are the zero tensor's: the separable passes, the hash and the worklist are skipped (a quarter of the
+    // tile's work); the filter stage runs as always.  (Not in self-check mode, which wants every pixel through both paths.)
+    const bool flat_tile = !DEFER && sCnt[3] == 0u && !P.cert_check;
 #ifdef RAISR_HIP_DEV
     if (PART == 2) {     // profiling aid: filter stage only; P.cert_check doubles as the bucket pattern (0 = every row of the bank, 1 = one row, 2 = sixteen rows)
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
@@ -409,6 +417,17 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         static_assert(RPW == 4, "the deferred exact path is built for the 64 x 16 tile");
         hash_phase_defer<LW, GT>(P, gw, S, sG, sV, sH, sH2, F, 4u * tile_id + (unsigned)w, c0, r0, tid);
         __builtin_amdgcn_wave_barrier();                    // rows [4w, 4w+4) of sH / sH2 are written and read by wave w only; LDS is in order within a wave
+    } else if (flat_tile) {
+        const int c = c0 + lane;
+        const bool inA = c >= P.a_begin && c < P.a_end, inB = c >= P.b_begin && c < P.b_end;
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {                      // rows [RPW w, RPW w + RPW) of sH / sH2 are written and read by wave w only
+            const int prow = RPW * w + j;
+            const bool zone = r0 + prow < P.H - kMargin && c < P.c_final && (inA || inB);
+            sH[prow * TW + lane] = zone ? (uint8_t)P.zero_bucket[inA ? 0 : 1] : (uint8_t)0xFFu;
+            sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)P.zero_bucket[1] : (uint8_t)0xFFu;
+        }
+        __builtin_amdgcn_wave_barrier();
     } else
     hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
     RAISR_PHASE_RESET;                                     // (the hash stage keeps its own marks 2..5)
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? RAISR_AC_WGS : 6) void k_hashfilter
     __shared__ uint8_t sH[TH * TW];
     __shared__ uint8_t sH2[TH * TW];
     __shared__ uint16_t sList[DEFER ? 1 : kListMax];      // worklist entries   (deferred variant: the list lives in global memory, FixAc)
-    __shared__ unsigned sCnt[DEFER ? 1 : 3];              // worklist length; uncertain pixels; certified-but-wrong (check mode)
+    __shared__ unsigned sCnt[DEFER ? 1 : 4];              // worklist length; uncertain pixels; certified-but-wrong (check mode); tile has a non-zero gradient
 
     int bx, by;
     xcd_tile(bx, by);
