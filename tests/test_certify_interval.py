@@ -137,7 +137,10 @@ def _constants():
     C["EL2_u"] = one(r"E_L2 = __builtin_fmaf\(([0-9.]+)f \* U1, T, E_L\)", ah, "E_L2")
     C["L2_min"] = one(r"ok &= L2 > ([0-9.]+)f \* E_L2", ah, "L2 > 2 E_L2")
     C["c055"] = one(r"__builtin_fmaf\(([0-9.]+)f, __builtin_fmaf\(E_L2,", ah, "0.55")
-    C["coh_add"] = one(r"S\.e24\[fl\]\), ([0-9.e-]+)f\);", ah, "coherence slack")
+    C["coh_mul"] = one(r"const float dcoh = __builtin_fmaf\(\(([0-9.]+)f \* t\) \* rho, r1t \* r1t,", ah, "coherence factor")
+    C["coh_add"] = one(r"rho, r1t \* r1t, ([0-9.e-]+)f\);", ah, "coherence slack")
+    C["rho_max"] = one(r"ok &= \(rho <= ([0-9.]+)f\)", ah, "rho <= 1/16")
+    assert "const float rho = __builtin_fmaf(" in ah and "S.e24[fl]);" in ah and "const float r1t = __builtin_amdgcn_rcpf(1.0f + t);" in ah
     C["xx_min"] = one(r"\(xx > ([0-9.]+)f \* E_L\)", ah, "xx > 2 E_L")
     C["drr_u"] = one(r"rD \* rD, ([0-9.]+)f \* U1\)", ah, "drr slack")
     C["dang_add"] = one(r"const float dang = drr \+ ([0-9.e-]+)f;", ah, "dang slack")
@@ -290,8 +293,9 @@ def test_root_eigenvalues_and_xx():
 
 
 def test_coherence_bound():
-    """s5: given |L1 - L1'| <= E_L = x1 L1', |L2 - L2'| <= E_L2 = x2 L2' with x2 <= 1/2 (the stage requires L2' > 2 E_L2):
-    |coh - coh'| <= 2 t' (0.55 (x2 / (1 - x2) + x1 / (1 - x1)) + 2.4 E) + 2e-6, for every t' = sqrt(L2'/L1') in [0, 1]."""
+    """s5: given |L1 - L1'| <= E_L = x1 L1', |L2 - L2'| <= E_L2 = x2 L2' with x2 <= 1/2 (the stage requires L2' > 2 E_L2), the kernel's
+    rho = 0.55 (x2 / (1 - x2) + x1 / (1 - x1)) + 2.4 E bounds |t_ref - t_k| / t' for every t' = sqrt(L2'/L1') (step 1); and with
+    rho <= 1/16 and coh = (1 - t) / (1 + t):  |coh - coh_k| <= 2.07 t_k rho r1t^2 + 2e-6 as the kernel evaluates it (step 2)."""
     C = _constants()
     x = np.concatenate([[0.0], np.geomspace(1e-9, 1.0, 361)])
     for flav, E in enumerate(C["E"]):
@@ -305,11 +309,19 @@ def test_coherence_bound():
         g = ((1.0 + X2) / (1.0 + X1)).sqrt() * (1.0 + sym(E)) / (1.0 + sym(E))
         tk_rel = ((1.0 + RND2) * (1.0 + RND)).sqrt() * (1.0 + RND2)
         dt_over_t = g - tk_rel                                 # (t_ref - t_k) / t'
-        # coh = (1 - t) / (1 + t): f(t_ref) - f(t_k) = -2 (t_ref - t_k) / ((1 + t_ref)(1 + t_k)); denominators >= 1
-        lhs = 2.0 * dt_over_t.abs_hi()                          # per unit of t'
-        # smallest value of the kernel's bound per unit of t' (its t is t_k >= t'(1 - 4u); five fp32 operations: relative 10 u)
-        rhs = 2.0 * (C["c055"] * (x2.lo / (1.0 - x2.lo) + x1.lo / (1.0 - x1.lo)) + C["e24"] * E) * (1 - 14 * U)
-        assert np.all(lhs <= rhs), ("coherence", flav, float((lhs / rhs).max()))
+        # smallest value of the kernel's rho (three fp32 operations + two v_rcp on top of exact inputs: relative 10 u), times
+        # t_k / t' >= 1 - 4 u
+        rho_lo = (C["c055"] * (x2.lo / (1.0 - x2.lo) + x1.lo / (1.0 - x1.lo)) + C["e24"] * E) * (1 - 14 * U)
+        assert np.all(dt_over_t.abs_hi() <= rho_lo), ("coherence, step 1", flav, float((dt_over_t.abs_hi() / rho_lo).max()))
+    # step 2.  d := |t_ref - t_k| <= t_k rho (step 1), rho <= rho_max, so 1 + t_ref >= 1 + t_k - t_k rho_max:
+    #   |f(t_ref) - f(t_k)| = 2 d / ((1 + t_ref)(1 + t_k)) <= 2 t_k rho / ((1 + t_k - t_k rho_max)(1 + t_k))
+    # against the kernel's coh_mul t_k rho r1t^2 with r1t = v_rcp(fl(1 + t_k)) (2 u + 1 ulp) and three more roundings; per unit of
+    # t_k rho, over t_k in [0, 1.001] (t_k = v_sqrt(L2 rL1) with L2 <= L1 up to roundings)
+    tk = IV(np.linspace(0.0, 1.001, 4097)[:-1], np.linspace(0.0, 1.001, 4097)[1:])
+    true_hi = (2.0 / ((1.0 + tk - tk * C["rho_max"]) * (1.0 + tk))).hi
+    r1 = 1.0 / (1.0 + tk) * (1.0 + RND) * (1.0 + RND2)
+    kern_lo = (C["coh_mul"] * (r1 * r1) * (1.0 + RND) * (1.0 + RND) * (1.0 + RND) * (1.0 + RND)).lo
+    assert np.all(true_hi <= kern_lo), ("coherence, step 2", float((true_hi / kern_lo).max()))
     # the additive slack covers what does not scale with t': four roundings of the reference's quotient, the 1e-17 in its denominator
     # (relative <= 1e-17 / sL1 <= 2.5e-10 for T >= 4e-15), the kernel's 1 - t, 1 + t, v_rcp, product
     assert 4 * U + 2.5e-10 + 6 * U <= C["coh_add"] * (1 - 1e-3)
