@@ -137,9 +137,10 @@ def _constants():
     C["EL2_u"] = one(r"E_L2 = __builtin_fmaf\(([0-9.]+)f \* U1, T, E_L\)", ah, "E_L2")
     C["L2_min"] = one(r"ok &= L2 > ([0-9.]+)f \* E_L2", ah, "L2 > 2 E_L2")
     C["c055"] = one(r"__builtin_fmaf\(([0-9.]+)f, __builtin_fmaf\(E_L2,", ah, "0.55")
-    C["coh_mul"] = one(r"const float dcoh = __builtin_fmaf\(\(([0-9.]+)f \* t\) \* rho, r1t \* r1t,", ah, "coherence factor")
-    C["coh_add"] = one(r"rho, r1t \* r1t, ([0-9.e-]+)f\);", ah, "coherence slack")
-    C["rho_max"] = one(r"ok &= \(rho <= ([0-9.]+)f\)", ah, "rho <= 1/16")
+    m = re.search(r"const float slope = rho <= ([0-9.]+)f \? ([0-9.]+)f \* \(r1t \* r1t\) : ([0-9.]+)f;", ah)
+    assert m, "cannot find the coherence slope in the sources: the test must follow the code"
+    C["rho_max"], C["coh_mul"], C["coh_mul_plain"] = (float(x) for x in m.groups())
+    C["coh_add"] = one(r"const float dcoh = __builtin_fmaf\(slope \* t, rho, ([0-9.e-]+)f\);", ah, "coherence slack")
     assert "const float rho = __builtin_fmaf(" in ah and "S.e24[fl]);" in ah and "const float r1t = __builtin_amdgcn_rcpf(1.0f + t);" in ah
     C["xx_min"] = one(r"\(xx > ([0-9.]+)f \* E_L\)", ah, "xx > 2 E_L")
     C["drr_u"] = one(r"rD \* rD, ([0-9.]+)f \* U1\)", ah, "drr slack")
@@ -295,7 +296,8 @@ def test_root_eigenvalues_and_xx():
 def test_coherence_bound():
     """s5: given |L1 - L1'| <= E_L = x1 L1', |L2 - L2'| <= E_L2 = x2 L2' with x2 <= 1/2 (the stage requires L2' > 2 E_L2), the kernel's
     rho = 0.55 (x2 / (1 - x2) + x1 / (1 - x1)) + 2.4 E bounds |t_ref - t_k| / t' for every t' = sqrt(L2'/L1') (step 1); and with
-    rho <= 1/16 and coh = (1 - t) / (1 + t):  |coh - coh_k| <= 2.07 t_k rho r1t^2 + 2e-6 as the kernel evaluates it (step 2)."""
+    rho <= 1/16 and coh = (1 - t) / (1 + t):  |coh - coh_k| <= 2.07 t_k rho r1t^2 + 2e-6 as the kernel evaluates it (step 2);
+    2 t_k rho + 2e-6 for larger rho."""
     C = _constants()
     x = np.concatenate([[0.0], np.geomspace(1e-9, 1.0, 361)])
     for flav, E in enumerate(C["E"]):
@@ -322,6 +324,8 @@ def test_coherence_bound():
     r1 = 1.0 / (1.0 + tk) * (1.0 + RND) * (1.0 + RND2)
     kern_lo = (C["coh_mul"] * (r1 * r1) * (1.0 + RND) * (1.0 + RND) * (1.0 + RND) * (1.0 + RND)).lo
     assert np.all(true_hi <= kern_lo), ("coherence, step 2", float((true_hi / kern_lo).max()))
+    # rho > rho_max: denominators >= 1, |f(t_ref) - f(t_k)| <= 2 d <= 2 t_k rho (1 - 8 u) against the kernel's two products
+    assert 2.0 * (1 - 8 * U) <= C["coh_mul_plain"] * (1 - 3 * U)
     # the additive slack covers what does not scale with t': four roundings of the reference's quotient, the 1e-17 in its denominator
     # (relative <= 1e-17 / sL1 <= 2.5e-10 for T >= 4e-15), the kernel's 1 - t, 1 + t, v_rcp, product
     assert 4 * U + 2.5e-10 + 6 * U <= C["coh_add"] * (1 - 1e-3)

@@ -22,8 +22,8 @@
 //               sqrt14(x) = sqrt(x)(1 + e), |e| <= E (1.0e-4 for VRCP14(VRSQRT14), 6.5e-4 for RCPPS(RSQRTPS); enumerated in
 //               tests/test_certify_bounds.py).  With s* = sqrt(R'):   |s - s*| <= E_s = 1.42 eps T' + (2e-7 + eps^2) T'^2 / s* + 1.05 E s*
 //   L1, L2, xx  |. - .*| <= E_L = E_s + (eps/2 + 6 u) T'   (L2* = (a'd' - b'^2) / L1* carries 4 u T' more)
-//   coherence   t = sqrt(L2/L1), rho = 0.55 (E_L2/(L2*-E_L2) + E_L/(L1*-E_L)) + 2.4 E: |coh - coh*| <= 2.07 t* rho / (1 + t*)^2 + 2e-6,
-//               needs L2* > 2 E_L2 and rho <= 1/16
+//   coherence   t = sqrt(L2/L1), rho = 0.55 (E_L2/(L2*-E_L2) + E_L/(L1*-E_L)) + 2.4 E: |coh - coh*| <= 2.07 t* rho / (1 + t*)^2 + 2e-6
+//               for rho <= 1/16, <= 2 t* rho + 2e-6 otherwise; needs L2* > 2 E_L2
 //   angle       rr = (xx - ay)/(xx + ay), |d rr| <= 2((ay+E_ay) E_L + (xx+E_L) E_ay) / (xx + ay - E_L - E_ay)^2 + 4 u,
 //               |P'(rr)| < 1 for the cubic P  =>  |ang_raw - ang_raw*| <= d rr + 1.5e-6;  q = ang 24/pi: + 2e-5
 // ------------------------------------------------------------------------------------------------
@@ -69,8 +69,10 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     // 1/32 of 1 + t: 2 / ((1 + t_ref)(1 + t)) <= 2.0646 / (1 + t)^2 (round 5: the factor 1 / (1 + t)^2 -- 0.39 at the threshold
     // coh = 0.41, 0.46 at 0.19 -- was bounded by 1, which sent twice as many pixels to the exact path for their coherence)
     const float rho = __builtin_fmaf(0.55f, __builtin_fmaf(E_L2, __builtin_amdgcn_rcpf(L2 - E_L2), E_L * __builtin_amdgcn_rcpf(L1 - E_L)), S.e24[fl]);
-    const float dcoh = __builtin_fmaf((2.07f * t) * rho, r1t * r1t, 2e-6f);
-    ok &= (rho <= 0.0625f) & (__builtin_fabsf(coh - Q.qc0) > dcoh) & (__builtin_fabsf(coh - Q.qc1) > dcoh);
+    // (rho > 1/16 -- 1-D structures, whose L2 is of the size of its own bound: the denominators are only known to be >= 1)
+    const float slope = rho <= 0.0625f ? 2.07f * (r1t * r1t) : 2.0f;
+    const float dcoh = __builtin_fmaf(slope * t, rho, 2e-6f);
+    ok &= (__builtin_fabsf(coh - Q.qc0) > dcoh) & (__builtin_fabsf(coh - Q.qc1) > dcoh);
     const int ci = (int)(Q.qc0 <= coh) + (int)(Q.qc1 <= coh);
     // angle
     const float E_b = S.eEb * T;
