@@ -102,47 +102,85 @@ __global__ __launch_bounds__(256) void k_resize(const TIn* __restrict__ src, TOu
 
 // 2x special case of the same arithmetic: weights {1,3}/4 per axis, out = (sum + 8) >> 4
 // (ties: +8 then >>4 is round-half-up; the half-even switch subtracts one when the discarded
-// bits are exactly 8 and the quotient is odd).  One thread produces 4 adjacent output pixels.
+// bits are exactly 8 and the quotient is odd).  One thread produces an 8 x 2 block of output pixels -- output rows 2 sy, 2 sy + 1 and
+// columns 8 t .. 8 t + 7 -- from source rows sy - 1, sy, sy + 1 and source columns 4 t - 1 .. 4 t + 4 (replicate-clamped): the
+// vertical sums 3 b + a / 3 b + c share 3 b, the horizontal ones share 3 v.  Round 5: the 4 x 1 version spent 29 vector
+// instructions per output pixel (3.8 M per 4K frame, 4 % of the pipeline's), this one 7; the kernel runs beside the other frames'
+// issue-bound k_hashfilter_ac, so its instructions are what it costs (docs/EXPERIMENTS.md R5.9).
+template <typename TIn>
+__device__ __forceinline__ void resize2x_row6(const TIn* __restrict__ src, unsigned row_off, const unsigned (&col)[6], int sh, int (&v)[6])
+{
+    // six single-sample loads at 32-bit offsets from the plane's (uniform) base: fewer vector instructions than one wide load plus
+    // its unpacking, and no branch for the planes' edges (planes are < 2^31 samples)
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = (int)src[row_off + col[k]];
+    if (sh) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] >>= sh;
+    }
+}
+
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
     src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     int bx, by;
     xcd_tile(bx, by);                                         // vertically adjacent blocks share input rows: keep them on one XCD
-    const int t = bx * 64 + (threadIdx.x & 63);               // group of 4 output columns
-    const int y = by * 4 + (threadIdx.x >> 6);
-    const int x0 = 4 * t;
-    if (x0 >= R.dw || y >= R.dh) return;
-    const int sy = y >> 1;
-    const int ya = (y & 1) ? sy : max(sy - 1, 0);             // far/near rows: even y -> (sy-1: 1, sy: 3)
-    const int yb = (y & 1) ? min(sy + 1, R.sh - 1) : sy;      //                odd  y -> (sy: 3, sy+1: 1)
-    const int wa = (y & 1) ? 3 : 1, wb = 4 - wa;
-    const TIn* ra = src + (size_t)ya * R.spitch;
-    const TIn* rb = src + (size_t)yb * R.spitch;
-    const int c = 2 * t;                                      // source columns c-1 .. c+2
-    const int cm = max(c - 1, 0), c1 = min(c + 1, R.sw - 1), c2 = min(c + 2, R.sw - 1), cc = min(c, R.sw - 1);
-    const int sh = R.in_shift;
-    const int a0 = ra[cm] >> sh, a1 = ra[cc] >> sh, a2 = ra[c1] >> sh, a3 = ra[c2] >> sh;
-    const int b0 = rb[cm] >> sh, b1 = rb[cc] >> sh, b2 = rb[c1] >> sh, b3 = rb[c2] >> sh;
-    const int v0 = wa * a0 + wb * b0, v1 = wa * a1 + wb * b1, v2 = wa * a2 + wb * b2, v3 = wa * a3 + wb * b3;
-    int o[4] = {v0 + 3 * v1, 3 * v1 + v2, v1 + 3 * v2, 3 * v2 + v3};
+    const int t = bx * 64 + (threadIdx.x & 63);               // group of 8 output columns
+    const int sy = by * 4 + (threadIdx.x >> 6);               // source row = pair of output rows
+    const int x0 = 8 * t, c = 4 * t;
+    if (x0 >= R.dw || sy >= R.sh) return;
+    int a[6], b[6], d[6];
+    unsigned col[6];                                          // source columns c - 1 .. c + 4, replicate-clamped (c itself is inside: 8 t < 2 sw)
+    col[0] = (unsigned)max(c - 1, 0); col[1] = (unsigned)c;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int q = (o[i] + 8) >> 4;
-        if (R.tie_even && ((o[i] & 15) == 8) && (q & 1)) q--;
-        o[i] = q << R.out_shift;
-    }
-    TOut* d = dst + (size_t)y * R.dpitch + x0;
-    if (x0 + 3 < R.dw) {
-        if (sizeof(TOut) == 2 && ((reinterpret_cast<uintptr_t>(d) & 7) == 0)) {
-            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
-        } else if (sizeof(TOut) == 1 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
-            *reinterpret_cast<unsigned*>(d) = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16) | ((unsigned)o[3] << 24);
-        } else {
-            d[0] = (TOut)o[0]; d[1] = (TOut)o[1]; d[2] = (TOut)o[2]; d[3] = (TOut)o[3];
+    for (int k = 2; k < 6; k++) col[k] = (unsigned)min(c - 1 + k, R.sw - 1);
+    resize2x_row6(src, (unsigned)max(sy - 1, 0) * (unsigned)R.spitch, col, R.in_shift, a);
+    resize2x_row6(src, (unsigned)sy * (unsigned)R.spitch, col, R.in_shift, b);
+    resize2x_row6(src, (unsigned)min(sy + 1, R.sh - 1) * (unsigned)R.spitch, col, R.in_shift, d);
+    int o[2][8];
+    {
+        int vt[6], vb[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int b3 = 3 * b[k];
+            vt[k] = b3 + a[k];                                // output row 2 sy:     (sy - 1: 1, sy: 3)
+            vb[k] = b3 + d[k];                                // output row 2 sy + 1: (sy: 3, sy + 1: 1)
         }
-    } else {
-        for (int i = 0; i < 4 && x0 + i < R.dw; i++) d[i] = (TOut)o[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t3 = 3 * vt[k + 1], u3 = 3 * vb[k + 1];
+            o[0][2 * k] = vt[k] + t3;     o[0][2 * k + 1] = t3 + vt[k + 2];
+            o[1][2 * k] = vb[k] + u3;     o[1][2 * k + 1] = u3 + vb[k + 2];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = 2 * sy + r;
+        if (y >= R.dh) break;
+        if (R.tie_even) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int q = (o[r][i] + 8) >> 4;
+                if (((o[r][i] & 15) == 8) && (q & 1)) q--;
+                o[r][i] = q << R.out_shift;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[r][i] = ((o[r][i] + 8) >> 4) << R.out_shift;
+        }
+        TOut* p = dst + (unsigned)y * (unsigned)R.dpitch + (unsigned)x0;
+        if (x0 + 7 < R.dw && (reinterpret_cast<uintptr_t>(p) & (8 * sizeof(TOut) - 1)) == 0) {
+            if (sizeof(TOut) == 1) {
+                *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)o[r][0] | ((unsigned)o[r][1] << 8) | ((unsigned)o[r][2] << 16) | ((unsigned)o[r][3] << 24),
+                                                          (unsigned)o[r][4] | ((unsigned)o[r][5] << 8) | ((unsigned)o[r][6] << 16) | ((unsigned)o[r][7] << 24));
+            } else {
+                *reinterpret_cast<uint4*>(p) = make_uint4((unsigned)o[r][0] | ((unsigned)o[r][1] << 16), (unsigned)o[r][2] | ((unsigned)o[r][3] << 16),
+                                                          (unsigned)o[r][4] | ((unsigned)o[r][5] << 16), (unsigned)o[r][6] | ((unsigned)o[r][7] << 16));
+            }
+        } else {
+            for (int i = 0; i < 8 && x0 + i < R.dw; i++) p[i] = (TOut)o[r][i];
+        }
     }
 }
 
