@@ -170,11 +170,14 @@ __device__ __forceinline__ void store_tile(const TileRegs<LH, LWLOAD, T>& R, TL*
         const int ty = w + 4 * it;
         if (ty < LH) sL[ty * LSTRIDE + lane] = (TL)(float)R.vm[it];
     }
+    // no `if (idx < NR)`: threads past the end loaded the LAST remainder sample (load_tile clamps idx) and store it to its own place
+    // again.  With the branch the compiler sank the last sweep's load into it, behind a wait for every earlier load: two global round
+    // trips in series at the head of every tile (round 5, R5.10).
 #pragma unroll
     for (unsigned it = 0; it < TR::NRL; it++) {
-        const unsigned idx = tid + 256u * it;
+        const unsigned idx = min(tid + 256u * it, TR::NR - 1u);
         const int ty = (int)(idx / TR::REM), tx = 64 + (int)(idx - (unsigned)ty * TR::REM);
-        if (idx < TR::NR) sL[ty * LSTRIDE + tx] = (TL)(float)R.vr[it];
+        sL[ty * LSTRIDE + tx] = (TL)(float)R.vr[it];
     }
 }
 

@@ -150,6 +150,15 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             return tree16(acc);
         };
         const bool anyB = sH2[prow * TW + lane] != 0xFFu;      // does this tile row contain re-hashed (tail) columns?
+        // symmetric stage: is this lane's pixel (column c0 + lane) in a non-palindromic bank row?  The bitmap word is requested here and
+        // used after the row's steps -- asked for there, its global round trip ended every row with an exposed s_waitcnt vmcnt(0)
+        // (round 5, R5.10: C2 +1.3 %)
+        unsigned asym_word = 0u, asym_key = 0u;
+        if (SYM && P.asym) {
+            const unsigned hrow = sH[prow * TW + lane];
+            asym_key = __umul24(hrow, (unsigned)P.pixel_types) + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
+            if (hrow != 0xFFu) asym_word = P.asym[asym_key >> 5];
+        }
         // The row's 16 steps (4 adjacent pixels each) share ONE summation tree.  sumitup_ps_512 halves the number of distinct
         // values per step at every level (16 lanes -> r8[0..7] -> r4[0..3] -> r2[0..1] -> v), so after each level two steps are
         // merged into one register (v_cndmask on a lane-index bit) and the next level runs once for both: 16 + 8 + 4 + 2 adds
@@ -253,9 +262,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         float keep = RAISR_LDS_F(ctr, sl);
         if (v > P.lo && v < P.hi) keep = v;
         if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
-            const unsigned hrow = sH[prow * TW + lane];
-            const unsigned key = hrow * (unsigned)P.pixel_types + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
-            const bool af = hrow != 0xFFu && ((P.asym[key >> 5] >> (key & 31u)) & 1u);
+            const bool af = (asym_word >> (asym_key & 31u)) & 1u;          // (0 for a pixel that is not filtered: its word was not loaded)
             const unsigned long long am = __ballot(af);
             if (am) {
 #pragma unroll 1
