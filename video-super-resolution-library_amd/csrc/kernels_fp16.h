@@ -565,8 +565,17 @@ __global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ l
     xcd_tile(bx, by);
     const int c0 = kMargin + bx * TW, r0 = kMargin + by * TH;
     lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
-    for (int i = threadIdx.x; i < 2048; i += 256) sTab[i] = Q.tab16[3072 + i];
-    stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL);
+    // the composite table (2048 binary16 entries): one 16-byte load per thread, in flight together with the window's loads.  (As a
+    // loop of 2-byte loads the compiler issued five, waited, and then ran the last three one round trip each: five global round
+    // trips in series at the head of every tile -- round 5, R5.10.)
+    static_assert(kGBytes % 16 == 0, "the table's LDS copy is 16-byte aligned");
+    const uint4 tab_part = reinterpret_cast<const uint4*>(Q.tab16 + 3072)[threadIdx.x];
+    {
+        TileRegs<LH, 76, T> Rg;
+        load_tile<LH, 76>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, Rg);
+        reinterpret_cast<uint4*>(sTab)[threadIdx.x] = tab_part;
+        store_tile<LH, 76, LW>(Rg, sL);
+    }
     __syncthreads();
     unsigned hA[R];
     hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA);
