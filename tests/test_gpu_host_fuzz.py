@@ -32,7 +32,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(int(os.environ.get("RAISR_HOST_FUZZ_N", "48")), 20260929),
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("RAISR_HOST_FUZZ_N", "48")), int(os.environ.get("RAISR_HOST_FUZZ_SEED", "20260929"))),
                          ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}b_a{c[3]}_p{c[4]}m{c[5]}_{c[6].split('_')[-1]}_{c[7]}_{c[9]}")
 def test_host_fuzz_case(case):
     import oracle_py as O
