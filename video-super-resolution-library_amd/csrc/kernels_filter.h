@@ -75,14 +75,27 @@ __device__ __forceinline__ float partner_xchg(float v)      // lane p of every r
 
 // filter_phase: the work of one 64 x 16 tile once its LR window is in LDS -- sP points at window position
 // (row r0-5, column c0-5), row stride LW -- and the tile's hashes are in sH / sH2 (0xFF = not filtered / no re-hash).
-template <int LW, int RPW = 4, bool SYM = false>
+//
+// PC ("pair columns", the production kernel): group g of step s = 2 p + j filters column 8 p + 2 g + j instead of 4 s + g, so the two
+// steps of a pair need ADJACENT window values per tap: one ds_read_b64 -- 2.8 LDS cycles per wave-instruction -- instead of one
+// ds_read2_b32 (two accesses 16 B apart: 4.7; scripts/lds_b64_probe.hip, profiles/r05_lds_b64_probe.log).  gfx950 serves an 8-byte
+// read at a 4-mod-8 address correctly but lane by lane (64 cycles), so every read must be aligned: the window's row stride is even
+// (LW = 76), which makes the alignment of tap (i, j) of an even column a function of j alone, and the taps that would be misaligned in
+// the window (even j: sP sits at an odd dword) read a second copy sQ of the filter window whose origin is aligned (sQ[e] == sP[e],
+// 26 x 76 floats; the caller builds it in LDS that is dead by then).  The type column (c - 5) & 1 = (j + 1) & 1 (c0 is even) no longer
+// depends on the lane: it travels in the coefficient loads' scalar offset.  Same operations on the same operands: the pixel -> lane
+// group assignment is free.
+template <int LW, int RPW = 4, bool SYM = false, bool PC = false>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
-                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x, const float* zpad = nullptr)
+                                             int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x, const float* zpad = nullptr,
+                                             const float* sQ = nullptr)
 {
     constexpr int TW = 64;
+    static_assert(!PC || (LW % 2) == 0, "pair columns: 8-byte window reads need an even row stride");
     const int lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l = lane & 15;
     int off[8];
+    const int copy_disp = PC ? (int)(sQ - sL) : 0;               // floats from a window position to the same position of the second copy
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
         int k = 16 * ch + l;
@@ -91,6 +104,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             k = l <= 8 ? 16 * ch + l2 : (ch == 4 ? kTaps : 16 * (ch - 1) + l2);   // l >= 9: padding step first, then taps ch = 4, 5, 6
         }
         off[ch] = (k < kTaps) ? (k / 11) * LW + (k % 11) : 0;   // padding taps: coefficient is +0, any finite pixel will do
+        if (PC && (k >= kTaps || ((k % 11) & 1) == 0)) off[ch] += copy_disp;      // even patch column (and the padding taps): the aligned copy
         asm volatile("" : "+v"(off[ch]));                      // one register per tap: left alone, the compiler keeps row and column part apart (16 VGPRs)
     }
     // SYM: step 4 is tap 64 + l2 times c3 for l <= 8 and the padding step for l >= 9, whose window address points at zpad (64 floats
@@ -100,8 +114,11 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
     // lane-major copy of the bank (k_lane_major_bank): the lane's coefficients of taps ch = 0..3 are one 16-byte load, ch = 4..7 the
     // one 256 B further on.
     const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.bank_lm), 0, P.bank_bytes, 0x00020000);
-    const int tcol = (P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
+    const int tcol = (!PC && P.pixel_types == 4) ? ((g + 1) & 1) : 0;        // (c-5)&1 with c = c0 + 4s + g, c0 even
     const unsigned lane_off = (unsigned)(tcol * kTapsPad + 4 * l) * 4u;      // byte offset of (type column part, zmm lane)
+    const unsigned tsoff[2] = {(PC && P.pixel_types == 4) ? (unsigned)(kTapsPad * 4) : 0u, 0u};     // PC: step parity j -> type column part
+#define RAISR_COL(s) (PC ? 8 * ((s) >> 1) + 2 * g + ((s) & 1) : 4 * (s) + g)
+#define RAISR_G0 (PC ? 2 * g : g)
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
 
 #pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
@@ -113,22 +130,22 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // LDS byte addresses of this lane's 8 taps (and the centre pixel) for step 0; step s adds the immediate 16*s
         const char* tap[8];
 #pragma unroll
-        for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + g + off[ch]);
+        for (int ch = 0; ch < 8; ch++) tap[ch] = reinterpret_cast<const char*>(sL + prow * LW + RAISR_G0 + off[ch]);
         if (SYM) tap[4] = l >= 9 ? reinterpret_cast<const char*>(zpad) : tap[4];
-        const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + g + 5 * LW + 5);
+        const char* ctr = reinterpret_cast<const char*>(sL + prow * LW + RAISR_G0 + 5 * LW + 5);
 #ifdef RAISR_PROBE_LDS_F                                         /* development builds: timing probe from kernels_probes.h */
 #define RAISR_LDS_F(p, s) RAISR_PROBE_LDS_F(p, s)
 #else
-#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + 16 * (s)))
+#define RAISR_LDS_F(p, s) (*reinterpret_cast<const float*>((p) + (PC ? 32 * ((s) >> 1) + 4 * ((s) & 1) : 16 * (s))))
 #endif
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define RAISR_BANK_F4(voff) __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, (voff), 0, 0)
+#define RAISR_BANK_F4(voff, s) __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, (voff), PC ? tsoff[(s) & 1] : 0u, 0)
         // The plain 16-lane chains of one step with all eight coefficients (tail re-hash and, in the symmetric variant, the pixels of
         // non-palindromic rows).  The symmetric variant has no registers for the plain tap offsets: it recomputes them here, behind
         // an opaque lane index so that they are not hoisted into the main loop's live range.
         auto plain_step = [&](int s, unsigned hb) -> float {
             const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
-            const u32x4 fa = RAISR_BANK_F4(voff), fb = RAISR_BANK_F4(voff + 256u);
+            const u32x4 fa = RAISR_BANK_F4(voff, s), fb = RAISR_BANK_F4(voff + 256u, s);
             float acc;
             if (!SYM) {
                 acc = RAISR_LDS_F(tap[0], s) * __uint_as_float(fa[0]);
@@ -137,7 +154,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             } else {
                 int lq = l;
                 asm volatile("" : "+v"(lq));
-                const float* base = sL + prow * LW + g + 4 * s;
+                const float* base = sL + prow * LW + RAISR_COL(s);
                 acc = 0.0f;
 #pragma unroll
                 for (int ch = 0; ch < 8; ch++) {
@@ -186,13 +203,13 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             }
             return acc + row_ror<0x128>(acc);                   // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
         };
-        auto load_q = [&](unsigned hb, float (&q)[8]) {           // v_mad_u32_u24 for the offset (the 32x32 form is a slow 64-bit mad)
+        auto load_q = [&](unsigned hb, float (&q)[8], int s) {    // v_mad_u32_u24 for the offset (the 32x32 form is a slow 64-bit mad)
             const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
-            const u32x4 fa = RAISR_BANK_F4(voff);
+            const u32x4 fa = RAISR_BANK_F4(voff, s);
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) q[ch] = __uint_as_float(fa[ch]);
             if (!SYM) {
-                const u32x4 fb = RAISR_BANK_F4(voff + 256u);
+                const u32x4 fb = RAISR_BANK_F4(voff + 256u, s);
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++) q[4 + ch] = __uint_as_float(fb[ch]);
             }
@@ -211,22 +228,41 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             float Q[16][8];
             float X[16][8];
             unsigned Hh[16];
-            auto issue_h = [&](int s) { Hh[s] = sH[prow * TW + 4 * s + g]; };
-            auto issue_x = [&](int s) {
+            // PC: the bucket bytes of a pair are adjacent -- one 2-byte read, unpacked where the coefficient loads are issued (pinned there:
+            // taken apart right behind the read, the unpacking would wait for it and expose the LDS latency in every pair)
+            auto issue_h = [&](int s) {
+                if constexpr (PC) { if (!(s & 1)) Hh[s] = *reinterpret_cast<const uint16_t*>(sH + prow * TW + RAISR_COL(s)); }
+                else Hh[s] = sH[prow * TW + RAISR_COL(s)];
+            };
+            auto bucket_of = [&](int s) -> unsigned {
+                if constexpr (PC) {
+                    if (!(s & 1)) { asm volatile("" : "+v"(Hh[s])); return Hh[s] & 0xFFu; }
+                    return Hh[s - 1] >> 8;
+                } else return Hh[s];
+            };
+            // the window values of both steps of pair p.  PC: ONE aligned 8-byte LDS read per tap (the cast states the alignment the two-copy
+            // layout guarantees; left to itself the compiler assumes 4 and emits ds_read2_b32 offset1:1)
+            typedef float f32x2a8 __attribute__((ext_vector_type(2), aligned(8)));
+            auto issue_xx = [&](int p) {
 #pragma unroll
-                for (int ch = 0; ch < 8; ch++) X[s][ch] = RAISR_LDS_F(tap[ch], s);
+                for (int ch = 0; ch < 8; ch++) {
+                    if constexpr (PC) {
+                        const f32x2a8 v = *reinterpret_cast<const f32x2a8*>(tap[ch] + 32 * p);
+                        X[2 * p][ch] = v.x; X[2 * p + 1][ch] = v.y;
+                    } else { X[2 * p][ch] = RAISR_LDS_F(tap[ch], 2 * p); X[2 * p + 1][ch] = RAISR_LDS_F(tap[ch], 2 * p + 1); }
+                }
             };
 #pragma unroll
             for (int s = 0; s < 2 * AHEAD + 2; s++) issue_h(s);
 #pragma unroll
-            for (int s = 0; s < 2 * AHEAD; s++) load_q(Hh[s], Q[s]);
-            issue_x(0); issue_x(1);
+            for (int s = 0; s < 2 * AHEAD; s++) load_q(bucket_of(s), Q[s], s);
+            issue_xx(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                if (p + AHEAD < 8) { load_q(Hh[2 * (p + AHEAD)], Q[2 * (p + AHEAD)]); load_q(Hh[2 * (p + AHEAD) + 1], Q[2 * (p + AHEAD) + 1]); }
+                if (p + AHEAD < 8) { load_q(bucket_of(2 * (p + AHEAD)), Q[2 * (p + AHEAD)], 0); load_q(bucket_of(2 * (p + AHEAD) + 1), Q[2 * (p + AHEAD) + 1], 1); }
                 if (p + AHEAD + 1 < 8) { issue_h(2 * (p + AHEAD + 1)); issue_h(2 * (p + AHEAD + 1) + 1); }
-                if (p + 1 < 8) { issue_x(2 * p + 2); issue_x(2 * p + 3); }
+                if (p + 1 < 8) issue_xx(p + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 A16[2 * p] = chain(X[2 * p], Q[2 * p]);
                 A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1]);
@@ -259,7 +295,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         RAISR_MERGE(v, D2[1], 0xaaaaaaaaaaaaaaaaull);
 #undef RAISR_MERGE
         const int sl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);     // the step whose pixel this lane keeps
-        float keep = RAISR_LDS_F(ctr, sl);
+        const int csl = RAISR_COL(sl) - RAISR_G0;                                              // the pixel's column in the tile, less the group's base
+        float keep = *reinterpret_cast<const float*>(ctr + 4 * csl);
         if (v > P.lo && v < P.hi) keep = v;
         if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
             const bool af = (asym_word >> (asym_key & 31u)) & 1u;          // (0 for a pixel that is not filtered: its word was not loaded)
@@ -267,16 +304,16 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             if (am) {
 #pragma unroll 1
                 for (int s = 0; s < 16; s++) {
-                    if (((am >> (4 * s)) & 0xFull) == 0) continue;
-                    const float v = plain_step(s, sH[prow * TW + 4 * s + g]);
-                    if (s == sl && ((am >> (4 * s + g)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
+                    if ((PC ? (am >> (8 * (s >> 1) + (s & 1))) & 0x55ull : (am >> (4 * s)) & 0xFull) == 0) continue;      // the step's pixels (PC: columns 8 p + j + {0, 2, 4, 6})
+                    const float v = plain_step(s, sH[prow * TW + RAISR_COL(s)]);
+                    if (s == sl && ((am >> RAISR_COL(s)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
                 }
             }
         }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
             for (int s = 0; s < 16; s++) {
-                const unsigned hB = sH2[prow * TW + 4 * s + g];
+                const unsigned hB = sH2[prow * TW + RAISR_COL(s)];
                 if (hB == 0xFFu) continue;
                 const float v = plain_step(s, hB);
                 if (s == sl) {
@@ -287,9 +324,11 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         }
 #undef RAISR_LDS_F
 #undef RAISR_BANK_F4
-        const int c = c0 + 4 * sl + g;
+        const int c = c0 + RAISR_G0 + csl;
         if (r < P.H - kMargin && c < P.c_final) hr[(size_t)r * P.hr_pitch + c] = keep;
     }
+#undef RAISR_COL
+#undef RAISR_G0
 }
 
 template <typename T>
@@ -369,11 +408,20 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
 // one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
-template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false, bool DEFER = false>
+// PC (pair columns, filter_phase): sQ is the place of the filter stage's second window copy -- inside sV's space, past the exact path's
+// table and tensors, dead once every wave has finished its H pass; copy_window fills it behind the hash stage's barrier.
+template <int LW>
+__device__ __forceinline__ void copy_window(const float* sL, float* sQ, unsigned tid)
+{
+#pragma unroll
+    for (unsigned i = tid; i < 26u * LW; i += 256u) sQ[i] = sL[LW + 1 + i];      // sQ[e] = sP[e], sP = sL + LW + 1: window position (r0 - 5, c0 - 5)
+}
+
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false, bool DEFER = false, bool PC = false>
 __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
                                                    uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
                                                    float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x,
-                                                   const FixAc& F = FixAc{}, unsigned tile_id = 0)
+                                                   const FixAc& F = FixAc{}, unsigned tile_id = 0, float* sQ = nullptr)
 {
     constexpr int TW = 64, TH = 4 * RPW;
     static_assert(LH == TH + 12 && GH == TH + 10, "window and gradient tile follow the tile height");
@@ -417,6 +465,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
 #ifdef RAISR_HIP_DEV
     if (PART == 2) {     // profiling aid: filter stage only; P.cert_check doubles as the bucket pattern (0 = every row of the bank, 1 = one row, 2 = sixteen rows)
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
+        if constexpr (PC) copy_window<LW>(sL, sQ, tid);
         __syncthreads();
     } else
 #endif
@@ -434,9 +483,10 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
             sH[prow * TW + lane] = zone ? (uint8_t)P.zero_bucket[inA ? 0 : 1] : (uint8_t)0xFFu;
             sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)P.zero_bucket[1] : (uint8_t)0xFFu;
         }
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (PC) { copy_window<LW>(sL, sQ, tid); __syncthreads(); }      // (flat_tile is the same in every thread)
+        else __builtin_amdgcn_wave_barrier();
     } else
-    hash_phase_ac<LW, GT, RPW>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid);
+    hash_phase_ac<LW, GT, RPW, PC>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid, sQ);
     RAISR_PHASE_RESET;                                     // (the hash stage keeps its own marks 2..5)
     if (P.write_hash) {
         const int c = c0 + lane;
@@ -458,7 +508,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     // wave's own rows of sV (row group w of channel 0: read by wave w's H pass only, which is over).
     float* zpad = DEFER ? reinterpret_cast<float*>(sV + w * GW_) : reinterpret_cast<float*>(sG) + 64 * w;
     if (SYM && PART != 1) zpad[lane] = 0.0f;
-    if (PART != 1) filter_phase<LW, RPW, SYM>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, zpad);
+    if (PART != 1) filter_phase<LW, RPW, SYM, PC>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, zpad, sQ);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
     RAISR_PHASE(6);
 }
@@ -473,23 +523,39 @@ __global__ __launch_bounds__(256, RPW == 4 ? RAISR_AC_WGS : 6) void k_hashfilter
                                                                          uint8_t* __restrict__ hash_out, float* __restrict__ hr, FixAc F = FixAc{})
 {
     constexpr int TW = 64, TH = 4 * RPW;
-    constexpr int LW = 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
-    __shared__ float sL[LH * LW];
+    // pair columns (filter_phase): the production variants; the deferred comparison pipeline and the 64 x 8 experiment keep the round-4 order
+    constexpr bool PC = RPW == 4 && !DEFER;
+    constexpr int LW = PC ? 78 : 77, LH = TH + 12, GW_ = 74, GH = TH + 10;
     using GT = typename GradOf<T>::type;
-    __shared__ GT sG[GH * GW_];
-    __shared__ typename FVec<RPW>::type sV[3 * 4 * GW_];
+    using VT = typename FVec<RPW>::type;
+    // One block of LDS, carved by hand: the second window copy's bank alignment against the window (below) needs known offsets.
+    constexpr unsigned oL = 0, oG = oL + LH * LW * 4, oV = oG + GH * GW_ * sizeof(GT), oH = oV + 3 * 4 * GW_ * sizeof(VT), oH2 = oH + TH * TW,
+                       oList = oH2 + TH * TW, oCnt = oList + (DEFER ? 1 : kListMax) * 2 + (DEFER ? 2 : 0), oEnd = oCnt + (DEFER ? 1 : 4) * 4;
+    static_assert(oG % 8 == 0 && oV % 16 == 0 && oCnt % 4 == 0, "LDS carving: alignment");
+    __shared__ __attribute__((aligned(256))) unsigned char smem[oEnd];
+    float* sL = reinterpret_cast<float*>(smem + oL);
+    GT* sG = reinterpret_cast<GT*>(smem + oG);
+    VT* sV = reinterpret_cast<VT*>(smem + oV);
     uint2* sTab = reinterpret_cast<uint2*>(sV);   // the exact path's table takes sV's place once the H pass is done (hash_phase_ac)
-    __shared__ uint8_t sH[TH * TW];
-    __shared__ uint8_t sH2[TH * TW];
-    __shared__ uint16_t sList[DEFER ? 1 : kListMax];      // worklist entries   (deferred variant: the list lives in global memory, FixAc)
-    __shared__ unsigned sCnt[DEFER ? 1 : 4];              // worklist length; uncertain pixels; certified-but-wrong (check mode); tile has a non-zero gradient
+    uint8_t* sH = smem + oH;
+    uint8_t* sH2 = smem + oH2;
+    uint16_t* sList = reinterpret_cast<uint16_t*>(smem + oList);      // worklist entries   (deferred variant: the list lives in global memory, FixAc)
+    unsigned* sCnt = reinterpret_cast<unsigned*>(smem + oCnt);        // worklist length; uncertain pixels; certified-but-wrong (check mode); tile has a non-zero gradient
+    // Second window copy of the pair-column filter stage: in sV's space behind the exact path's table (1 KB) and tensors (kListMax x 16 B),
+    // 26 x LW floats.  Its dword offset from the window, mod 64, decides the bank conflicts of the stage's 8-byte reads (two groups of 32
+    // lanes, 64 banks): with LW = 78 the offsets 0, 2, 40, 42 are conflict-free for every tap chunk of both stage variants
+    // (tests/test_filter_window_banks.py replays the bank arithmetic); 3680 B into sV gives 40.
+    constexpr unsigned oQ = oV + 3680;
+    static_assert(!PC || (oQ >= oV + 1024 + kListMax * 16 && oQ + 26 * LW * 4 <= oH && oQ % 8 == 0), "second window copy: inside sV, past table and tensors");
+    static_assert(!PC || (((oQ - oL) / 4) % 64 == 40), "second window copy: conflict-free bank offset");
+    float* sQ = PC ? reinterpret_cast<float*>(smem + oQ) : nullptr;
 
     int bx, by;
     xcd_tile(bx, by);
     by += P.tile_y0;
     lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
     const unsigned tile_id = blockIdx.z * F.zs_tiles + (unsigned)by * (unsigned)F.tiles_x + (unsigned)bx;
-    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM, DEFER>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, threadIdx.x, F, tile_id);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM, DEFER, PC>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, threadIdx.x, F, tile_id, sQ);
 }
 
 

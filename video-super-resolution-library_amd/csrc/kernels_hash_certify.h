@@ -250,10 +250,10 @@ constexpr unsigned kListMax = 160;
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
-template <int LW, typename GT, int RPW = 4>
+template <int LW, typename GT, int RPW = 4, bool PC = false>
 __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW& gw, const SepW& S, const float* sL, GT* sG, typename FVec<RPW>::type* sV,
                                               const uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt,
-                                              int c0, int r0, unsigned tid = threadIdx.x)
+                                              int c0, int r0, unsigned tid = threadIdx.x, float* sQ = nullptr)
 {
     constexpr int GW_ = 74, TW = 64;
     const int lane = tid & 63, w = tid >> 6;
@@ -298,6 +298,12 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     RAISR_PHASE(3);                                        // approximate hash + certification
     __syncthreads();
     RAISR_PHASE(4);                                        // ... wait for the other waves
+    // pair-column filter stage: its second window copy goes into sV's space now that every wave is past its H pass (behind the table
+    // and the tensors of the exact path); the barriers of the worklist -- or the one at the end -- publish it
+    if constexpr (PC) {
+#pragma unroll
+        for (unsigned i = tid; i < 26u * LW; i += 256u) sQ[i] = sL[LW + 1 + i];
+    }
 
     // ---- worklist: the exact path for what could not be certified ----
     const unsigned n = sCnt[0];
@@ -353,7 +359,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         }
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
-    if (n) __syncthreads();                                // (n is the same in every thread)
+    if (n || PC) __syncthreads();                          // (n is the same in every thread)
     RAISR_PHASE(5);                                        // worklist: table staging, exact tensors, exact hashes, three barriers
 }
 
