@@ -229,7 +229,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             float X[16][8];
             unsigned Hh[16];
             // PC: the bucket bytes of a pair are adjacent -- one 2-byte read, unpacked where the coefficient loads are issued (pinned there:
-            // taken apart right behind the read, the unpacking would wait for it and expose the LDS latency in every pair)
+            // taken apart right behind the read, the unpacking would wait for it and expose the LDS latency in every pair).  Two 1-byte
+            // reads instead: -0.3 % on C2; two pairs of look-ahead (AHEAD = 2, 102 VGPRs): +-0 (profiles/r05_paircol_variants_ab.log)
             auto issue_h = [&](int s) {
                 if constexpr (PC) { if (!(s & 1)) Hh[s] = *reinterpret_cast<const uint16_t*>(sH + prow * TW + RAISR_COL(s)); }
                 else Hh[s] = sH[prow * TW + RAISR_COL(s)];
