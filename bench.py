@@ -426,8 +426,8 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
                           "frac": round(floor_ms / iso[dom], 4) if dom in iso else None,
                           "what": "vector-L1 delivery floor of the filter stage's coefficients / isolated launch of the dominant kernel (a floor, not the bound)"}
         if not fp16:
-            roofline["binding"] = ("instruction issue at 16 waves per CU with no pipe saturated: vector ALU ~55 % (at the 2.7 cycles per v_fma_f32 the part "
-                                   "sustains), LDS ~60 %, vector L1 ~40 % (~63 % for models whose bank is not symmetric) of the kernel's cycles; a fifth workgroup "
+            roofline["binding"] = ("instruction issue at 16 waves per CU with no pipe saturated: vector ALU ~61 % (at the 2.7 cycles per v_fma_f32 the part "
+                                   "sustains), LDS ~43 % (60 % before the filter stage's 8-byte window reads, R5.11), vector L1 ~40 % (~63 % for models whose bank is not symmetric) of the kernel's cycles; a fifth workgroup "
                                    "per CU, prefetching and barrier removal change nothing, removing instructions does (rocprofv3 SQ counters and timing "
                                    "probes, docs/EXPERIMENTS.md I.1, I.4); fp32-valu utilisation is the figure to watch")
     return roofline
