@@ -4,8 +4,8 @@ Round 3 matrix: 8-bit 2x (three models, both hash flavours, 2-pass mode 1 -- the
 (synthesised `_16` folder), 1.5x (one pixel type) and 2-pass mode 2 (pass 1 at input size), each on natural / noise /
 smooth-gradient-with-edges frames.  Round 5 (KINDS=r05): three more frame families on the same matrix -- ramps (linear gradients of
 integer and fractional slope in every orientation, piecewise: long runs of identical windows, exact symmetries), text-like edges
-(two-level glyph strokes 1-3 px wide on flat or gently shaded ground) and film grain (natural frames + Gaussian grain).
-Usage: [KINDS=r05] certify_campaign.py [frames per kind] -> gpurun_out/certify_campaign.json"""
+(two-level glyph strokes 1-3 px wide on flat or gently shaded ground) and film grain (natural frames + Gaussian grain).  Round 6 (KINDS=photo): real photographs (photos.py).
+Usage: [KINDS=r05|photo] certify_campaign.py [frames per kind] -> gpurun_out/certify_campaign.json"""
 import json, os, shutil, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,13 @@ MATRIX = [
 
 
 def frames(i, w, h, bits):
+    if os.environ.get("KINDS") == "photo":
+        # round 6: REAL pictures (photos.py: the photographs installed with this image's Python packages; plain / JPEG-blocky / letterboxed /
+        # enlarged / mosaic).  Three frames per i; 13 is coprime with sources x variants, so 35 values of i visit every (source, variant) pair.
+        import photos
+        if bits == 16:
+            return [(photos.photo_y(w, h, 10, 13 * (3 * i + k)).astype(np.uint32) * 64 + rng.integers(0, 64, (h, w))).astype(np.uint16) for k in range(3)]
+        return [photos.photo_y(w, h, bits, 13 * (3 * i + k)) for k in range(3)]
     maxv = (1 << bits) - 1
     lo, hi = (16 * maxv // 255, 235 * maxv // 255)
     if bits == 16:                              # 10-bit generators scaled up, with low-order noise so that all 16 bits are in play
@@ -106,6 +113,8 @@ for key, fold, w, h, ow, oh, bits, passes, mode, asm, full, nn in MATRIX:
     assert st["mismatches"] == 0, (key, st)
 shutil.rmtree(tmp, ignore_errors=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump({"frames_per_kind": n, "kinds": ["ramps", "text-like edges", "film grain"] if os.environ.get("KINDS") == "r05" else ["natural", "noise", "smooth gradients with hard edges"],
+KIND_NAMES = {"r05": ["ramps", "text-like edges", "film grain"],
+              "photo": ["photographs (photos.py), three frames per index: plain / jpeg30 / letterbox / soft2x / mosaic variants of the installed sample pictures"]}
+json.dump({"frames_per_kind": n, "kinds": KIND_NAMES.get(os.environ.get("KINDS"), ["natural", "noise", "smooth gradients with hard edges"]),
            "buckets_compared": sum(v["pixels"] for v in tot.values()), "certified_but_wrong": sum(v["mismatches"] for v in tot.values()),
            "results": tot}, open(os.path.join(ROOT, "gpurun_out", "certify_campaign.json"), "w"), indent=1)

@@ -15,6 +15,8 @@ BASELINE = [
     ("C3_1080p_highres_2p", "filters_2x/filters_highres", (2, 1), 8, 2, 1, 2, False, (1920, 1080)),
     ("C4_720p_1.5x_denoise_fp16_2p_m2", "filters_1.5x/filters_denoise", (3, 2), 8, 2, 2, 5, False, (1280, 720)),
     ("C5_4k_8k_10bit", "filters_2x/filters_highres", (2, 1), 10, 1, 1, 2, False, (3840, 2160)),
+    # not a BASELINE.json config: the one the reference publishes its numbers on (docs/performance.md:8-14), bench.py's C2b leg
+    ("C2b_1080p_highres_1p_10bit", "filters_2x/filters_highres", (2, 1), 10, 1, 1, 2, False, (1920, 1080)),
 ]
 
 
