@@ -363,7 +363,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     RAISR_PHASE(5);                                        // worklist: table staging, exact tensors, exact hashes, three barriers
 }
 
-// hash_phase_defer: the hash stage of k_hashfilter_ac<.., DEFER> (the production kernel).  As hash_phase_ac up to the certification;
+// hash_phase_defer: the hash stage of k_hashfilter_ac<.., DEFER> -- a COMPARISON pipeline (test-hooks / development flavours only:
+// RAISR_HIP_DEFER; measured 1-6 % slower than the in-tile worklist of hash_phase_ac, docs/EXPERIMENTS.md R5.1; the product runs
+// hash_phase_ac).  As hash_phase_ac up to the certification;
 // then every wave is on its own: the pixels it could not certify keep their approximate bucket for the filter stage and go, with
 // that bucket, into the wave's region of the frame's fix list (FixAc; k_fix_ac repairs those whose exact bucket differs before
 // k_blend reads the HR plane).  A wave with more than kWaveCap of them (synthetic content: 1-px patterns, exact symmetries) runs

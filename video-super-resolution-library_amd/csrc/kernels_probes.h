@@ -15,13 +15,13 @@
 #endif
 // On the compiler's own schedule.  RAISR_EXP_COEF_REUSE = n: coefficients are fetched for every n-th step only and reused for the steps
 // between -- what a key-chunked stage could gain at most, with its sort, scattered window reads and scattered stores for free.
-// (Expands inside filter_phase's row loop: load_q, chain, tap[], sH, prow, g, A16 are the names of that scope.)
+// (Expands inside filter_phase's row loop: load_q(bucket, q, step), chain, tap[], sH, prow, RAISR_COL, A16 are the names of that scope.)
 #define RAISR_PROBE_FILTER_STEPS                                                                           \
         {                                                                                                  \
             float qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                        \
             _Pragma("unroll")                                                                              \
             for (int s = 0; s < 16; s++) {                                                                 \
-                if (s % RAISR_EXP_COEF_REUSE == 0) load_q(sH[prow * TW + 4 * s + g], qr);                  \
+                if (s % RAISR_EXP_COEF_REUSE == 0) load_q(sH[prow * TW + RAISR_COL(s)], qr, s);               \
                 float x[8];                                                                                \
                 _Pragma("unroll")                                                                          \
                 for (int ch = 0; ch < 8; ch++) x[ch] = RAISR_LDS_F(tap[ch], s);                            \
