@@ -639,6 +639,10 @@ def certify_leg(R, wl, gpu, blobs, frames):
             res["buckets_compared"] = st["pixels"]
         else:
             res["uncertified_frac"] = round(st["uncertain"] / max(1, st["pixels"]), 6)
+            if st.get("tiles"):            # the worklist per 64 x 16 tile: tiles with a non-empty list; tiles whose list overflowed (all-exact stage)
+                res["tiles_listed_frac"] = round(st["tiles_listed"] / st["tiles"], 4)
+                res["tiles_overflow_frac"] = round(st["tiles_overflow"] / st["tiles"], 4)
+                res["tiles_flat_frac"] = round(st["tiles_flat"] / st["tiles"], 4)
     res["frames"] = len(frames)
     return res
 
@@ -899,7 +903,8 @@ def main():
                             d.close()
                         cert = certify_leg(R, wl, gpu, blobs, fr if kind == "photo" else fr[:2])
                         out[kind] = {"fps": round(n / dtk, 2), "value": round(wl.out_w * wl.out_h * n / dtk / 1e6, 2),
-                                     "uncertified_frac": cert.get("uncertified_frac"), "certified_wrong": cert.get("certified_wrong")}
+                                     "uncertified_frac": cert.get("uncertified_frac"), "certified_wrong": cert.get("certified_wrong"),
+                                     "tiles_listed_frac": cert.get("tiles_listed_frac"), "tiles_overflow_frac": cert.get("tiles_overflow_frac")}
                     out["what"] = f"C2, {args.extra_frames} frames per kind, {args.lanes} lanes; `value` of this line is the `{args.frame_kind}` kind on {frames_total} frames"
                     return out
                 leg("frame_kinds", kinds_leg)

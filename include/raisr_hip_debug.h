@@ -24,10 +24,17 @@ int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash
  *   collect != 0: count, over the frames processed from now on, {pixels sent to the exact path, certified buckets that
  *                 differed from the exact ones (only counted with check != 0; must stay 0), filtered pixels};
  *   check   != 0: self-check mode -- EVERY pixel also takes the exact path and certified buckets are compared with it.
- * raisr_hip_debug_certify_stats() synchronises the context's stream and reads the three counters.
+ * raisr_hip_debug_certify_stats() synchronises the context's stream and reads the counters: out[0..2] as above, then the per-tile view
+ * of the worklist -- out[3] tiles (64 x 16 pixels) with a non-empty list, out[4] tiles whose list overflowed (they pay the approximate
+ * AND the all-exact stage), out[5] tiles processed, out[6] flat tiles (hash stage skipped), out[7] reserved; read out[3..6] from a run
+ * without the self-check, which lists every pixel.
  * Replaces nothing in the reference; it is the observability of an optimisation the reference does not have. */
 int raisr_hip_debug_certify(raisr_hip_ctx *ctx, int collect, int check);
-int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[3]);
+int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[8]);
+/* Class-1 sign table of the certified hash stage (exactly one-dimensional windows, docs/CERTIFY.md s9): 65 536 bytes, entry i = the floats
+ * whose mantissa >> 7 is i; bit 0: some a of them has fl(a/2 - VRCP14(VRSQRT14(fl(a a)/4))) < 0, bit 1: some has it >= 0.
+ * RAISR_HIP_ESTATE when the class is switched off (RAISR_HIP_C1=0 at context creation). */
+int raisr_hip_debug_read_c1tab(raisr_hip_ctx *ctx, uint8_t *out65536);
 /* Decision of the certified hash stage for `n` host-side APPROXIMATE tensor triples (a', b', d'): the bucket it computes and
  * whether it certifies it (1) or would send the pixel to the exact path (0), by the device function the kernels run.
  * *eps_out (optional) receives the relative tensor error eps the certification assumes: a certified bucket must equal the

@@ -137,7 +137,7 @@ def _constants():
     C["EL2_u"] = one(r"E_L2 = __builtin_fmaf\(([0-9.]+)f \* U1, T, E_L\)", ah, "E_L2")
     C["L2_min"] = one(r"ok &= L2 > ([0-9.]+)f \* E_L2", ah, "L2 > 2 E_L2")
     C["c055"] = one(r"__builtin_fmaf\(([0-9.]+)f, __builtin_fmaf\(E_L2,", ah, "0.55")
-    m = re.search(r"const float slope = rho <= ([0-9.]+)f \? ([0-9.]+)f \* \(r1t \* r1t\) : ([0-9.]+)f;", ah)
+    m = re.search(r"const float slope = \(\(rho <= ([0-9.]+)f\) & \(t <= 1\.0f\)\) \? ([0-9.]+)f \* \(r1t \* r1t\) : ([0-9.]+)f;", ah)
     assert m, "cannot find the coherence slope in the sources: the test must follow the code"
     C["rho_max"], C["coh_mul"], C["coh_mul_plain"] = (float(x) for x in m.groups())
     C["coh_add"] = one(r"const float dcoh = __builtin_fmaf\(slope \* t, rho, ([0-9.e-]+)f\);", ah, "coherence slack")

@@ -139,7 +139,7 @@ def certify(a, b, d, P, eps, E14):
         coh = (f(1) - t) / (f(1) + t)
         rho = f(0.55) * (E_L2 / (L2 - E_L2) + E_L / (L1 - E_L)) + f(2.4 * E14)
         r1t = f(1) / (f(1) + t)
-        slope = np.where(rho <= f(0.0625), f(2.07) * (r1t * r1t), f(2.0))   # round 5: 1 / (1 + t)^2 of d coh / dt kept (was bounded by 1)
+        slope = np.where((rho <= f(0.0625)) & (t <= f(1.0)), f(2.07) * (r1t * r1t), f(2.0))   # round 5: 1 / (1 + t)^2 of d coh / dt kept (was bounded by 1)
         dcoh = (slope * t) * rho + f(2e-6)
         c_coh = okc & (np.abs(coh - qc[0]) > dcoh) & (np.abs(coh - qc[1]) > dcoh)
         ci = (qc[0] <= coh).astype(np.int32) + (qc[1] <= coh)

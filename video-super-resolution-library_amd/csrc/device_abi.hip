@@ -198,6 +198,7 @@ SepW make_sep(const GaussW& g)
     S.eEL = (float)(0.5 * eps + 6.0 * u);
     S.eEb = (float)(0.5 * eps);
     for (int f = 0; f < 2; f++) { S.e105[f] = (float)(1.05 * E[f]); S.e24[f] = (float)(2.4 * E[f]); }
+    S.c1e = (float)(1.05 * eps);
     return S;
 }
 
@@ -263,7 +264,7 @@ struct raisr_hip_ctx {
     size_t fix_tiles = 0;
 #endif
     int cert_check = 0;                        // tests: every pixel also takes the exact path, certified buckets are compared
-    unsigned* d_cert_stats = nullptr;          // {uncertain, certified-but-wrong, zone pixels}, accumulated while non-null
+    unsigned* d_cert_stats = nullptr;          // 8 counters {uncertain, certified-but-wrong, zone pixels, tiles with a list, overflowed tiles, tiles, flat tiles, -}, accumulated while non-null
     SepW sep{};
     int keep_hash_plane = 0;                   // fused kernel also writes the hash plane (set by raisr_hip_debug_read_stage users)
     raisr_hip_config cfg{};
@@ -272,6 +273,7 @@ struct raisr_hip_ctx {
     ModelDev model[2];
     // shared small tables
     uint2* d_tab14 = nullptr;
+    uint8_t* d_c1tab = nullptr;                // class-1 sign table (k_build_c1tab), 64 KB; null when RAISR_HIP_C1=0
     uint16_t* d_lut = nullptr;
     uint16_t* d_tab16 = nullptr;                // rcpph T, rsqrtph T0, T1
     GaussW16 gauss16{};
@@ -382,6 +384,12 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.bank_bytes = (int)blob_f32_bytes(m.h.hashkeys * m.h.pixel_types);
     P.bank_lm = m.bank_lm;
     P.tab14 = c->d_tab14;
+    P.c1tab = c->d_c1tab;
+    {   // class-1 rule (kernels_hash_certify.h): a window with L2 >= 0 has coherence >= 0.985 (AVX2 flavour: 0.964) -- index 2 needs both
+        // thresholds below that (every shipped model: <= 0.48)
+        const float qmax = m.h.qcoh[0] > m.h.qcoh[1] ? m.h.qcoh[0] : m.h.qcoh[1];
+        P.c1_ok = (qmax < 0.98f ? 1 : 0) | (qmax < 0.96f ? 2 : 0);
+    }
     P.lut_legacy = c->d_lut;
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
     P.gauss_dev = c->d_gauss;
@@ -841,6 +849,14 @@ static int create_impl(raisr_hip_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->d_lut, lut.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(c->d_tab14, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {   // class-1 sign table of the certified hash stage, from the exact device models (RAISR_HIP_C1=0: the class goes to the worklist as before round 6)
+        const char* e = getenv("RAISR_HIP_C1");
+        if (!(e && e[0] == '0')) {
+            HIP_TRY(hipMalloc((void**)&c->d_c1tab, kC1Buckets));
+            hipLaunchKernelGGL(k_build_c1tab, dim3(kC1Buckets / 256), dim3(256), 0, c->stream, c->d_tab14, c->d_c1tab);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
     std::vector<uint16_t> t16(3072 + 2048);
     for (int i = 0; i < 1024; i++) { t16[i] = X86_RCPPH_T[i]; t16[1024 + i] = X86_RSQRTPH_T0[i]; t16[2048 + i] = X86_RSQRTPH_T1[i]; }
     // composite VRCPPH(VRSQRTPH(x)) for positive finite x (kernels_fp16.h, sqrt_ph): VRSQRTPH gives mantissa + exponent te of row t
@@ -896,6 +912,7 @@ void raisr_hip_destroy(raisr_hip_ctx* c)
     for (int i = 0; i < 2; i++) if (c->model[i].d_asym) (void)hipFree(c->model[i].d_asym);
     for (int i = 0; i < 2; i++) if (c->model[i].bank_lm) (void)hipFree(c->model[i].bank_lm);
     if (c->d_tab14) (void)hipFree(c->d_tab14);
+    if (c->d_c1tab) (void)hipFree(c->d_c1tab);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_tab16) (void)hipFree(c->d_tab16);
     if (c->d_cert_stats) (void)hipFree(c->d_cert_stats);
@@ -1893,20 +1910,30 @@ int raisr_hip_debug_certify(raisr_hip_ctx* c, int collect, int check)
     if (!c) return fail(RAISR_HIP_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (collect && !c->d_cert_stats) HIP_TRY(hipMalloc((void**)&c->d_cert_stats, 3 * sizeof(unsigned)));
-    if (c->d_cert_stats) { HIP_TRY(hipMemsetAsync(c->d_cert_stats, 0, 3 * sizeof(unsigned), c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    if (collect && !c->d_cert_stats) HIP_TRY(hipMalloc((void**)&c->d_cert_stats, 8 * sizeof(unsigned)));
+    if (c->d_cert_stats) { HIP_TRY(hipMemsetAsync(c->d_cert_stats, 0, 8 * sizeof(unsigned), c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     if (!collect && c->d_cert_stats) { (void)hipFree(c->d_cert_stats); c->d_cert_stats = nullptr; }
     c->cert_check = check != 0;
     return RAISR_HIP_OK;
 }
 
-int raisr_hip_debug_certify_stats(raisr_hip_ctx* c, unsigned out[3])
+int raisr_hip_debug_certify_stats(raisr_hip_ctx* c, unsigned out[8])
 {
     if (!c || !out) return fail(RAISR_HIP_EINVAL, "null argument");
     if (!c->d_cert_stats) return fail(RAISR_HIP_ESTATE, "statistics are not being collected");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_cert_stats, 3 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, c->d_cert_stats, 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return RAISR_HIP_OK;
+}
+
+// Test hook: the class-1 sign table of the certified hash stage as the context built it (65 536 bytes); ESTATE when the class is off.
+int raisr_hip_debug_read_c1tab(raisr_hip_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return fail(RAISR_HIP_EINVAL, "null argument");
+    if (!c->d_c1tab) return fail(RAISR_HIP_ESTATE, "the class-1 rule is switched off (RAISR_HIP_C1=0)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(out, c->d_c1tab, kC1Buckets, hipMemcpyDeviceToHost));
     return RAISR_HIP_OK;
 }
 

@@ -32,7 +32,9 @@ struct PassParams {
     const uint2* tab14;          // [128]: rcp14 {C0,C1}[64], rsqrt14 {C0,C1}[64]
     const uint16_t* lut_legacy;  // rcp[2048], rsqrt[2048]
     int write_hash;              // fused kernel: also write the hash plane (introspection for tests)
-    unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels} or null
+    const uint8_t* c1tab;        // class-1 (exactly one-dimensional windows) sign table of kernels_hash_certify.h, or null: class switched off
+    int c1_ok;                   // bit 0 / 1: this model's coherence thresholds admit the class-1 rule in the AVX-512 / AVX2 flavour
+    unsigned* cert_stats;        // certified-hash kernel: {pixels sent to the exact path, certified-but-wrong, zone pixels, tiles with a list, overflowed tiles, tiles, flat tiles, -} or null
     int cert_check;              // 1: every pixel also takes the exact path and certified buckets are compared with it (tests)
     int zero_bucket[2];          // bucket of the all-zero tensor in the AVX-512 / AVX2 flavour (flat windows), from the exact device code
     const float* gauss_dev;      // GaussW::wT as a device array [11][12] (per-lane weights of the 16-lane exact tensor)

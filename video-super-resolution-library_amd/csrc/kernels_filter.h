@@ -502,6 +502,12 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         if (!DEFER && sCnt[1]) atomicAdd(&P.cert_stats[0], sCnt[1]);
         if (!DEFER && sCnt[2]) atomicAdd(&P.cert_stats[1], sCnt[2]);
         atomicAdd(&P.cert_stats[2], (unsigned)(max(zr, 0) * max(zc, 0)));
+        // per-tile view of the worklist (meaningful without the self-check, which lists every pixel): tiles with a non-empty list, tiles
+        // whose list overflowed (they pay the approximate AND the all-exact stage), tiles seen, flat tiles (hash stage skipped)
+        if (!DEFER && !flat_tile && sCnt[0]) atomicAdd(&P.cert_stats[3], 1u);
+        if (!DEFER && !flat_tile && sCnt[0] > kListMax) atomicAdd(&P.cert_stats[4], 1u);
+        atomicAdd(&P.cert_stats[5], 1u);
+        if (flat_tile) atomicAdd(&P.cert_stats[6], 1u);
     }
     // symmetric stage: 64 floats of +0 per wave in the gradient tile's space (every wave is past its last read of sG: the hash
     // stage's last use of it lies before a workgroup barrier); written and read by the same wave, LDS operations of a wave run in order.

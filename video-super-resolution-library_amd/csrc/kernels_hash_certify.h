@@ -32,12 +32,14 @@ struct SepW {
     float es1, es2;              // 1.42 eps, 2e-7 + eps^2
     float eEL, eEb;              // eps/2 + 6 u, eps/2
     float e105[2], e24[2];       // 1.05 E and 2.4 E for the AVX-512 (0) and the AVX2 (1) approximation instructions
+    float c1e;                   // 1.05 eps: half-width of the box around a' that contains the reference's a (one-dimensional windows, class1_hash)
 };
 
 struct HashQf { float qangle, qs0, qs1, qc0, qc1; };
 
 // returns true when the bucket is certified
-__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, unsigned& bucket)
+__device__ __forceinline__ bool approx_hash(float a, float b, float d, const HashQf Q, const SepW& S, int fl, unsigned& bucket,
+                                            int* si_out = nullptr, bool* ok_str_out = nullptr)
 {
     const float U1 = 5.9604645e-8f;                      // 2^-24
     const float pi = 3.141592653f;
@@ -60,6 +62,8 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     // strength
     ok &= (__builtin_fabsf(L1 - Q.qs0) > E_L) & (__builtin_fabsf(L1 - Q.qs1) > E_L);
     const int si = (int)(Q.qs0 <= L1) + (int)(Q.qs1 <= L1);
+    if (si_out) *si_out = si;
+    if (ok_str_out) *ok_str_out = ok;                    // preconditions of the root bound + strength index certified
     // coherence
     ok &= L2 > 2.0f * E_L2;
     const float t = __builtin_amdgcn_sqrtf(L2 * rL1);
@@ -70,7 +74,8 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     // coh = 0.41, 0.46 at 0.19 -- was bounded by 1, which sent twice as many pixels to the exact path for their coherence)
     const float rho = __builtin_fmaf(0.55f, __builtin_fmaf(E_L2, __builtin_amdgcn_rcpf(L2 - E_L2), E_L * __builtin_amdgcn_rcpf(L1 - E_L)), S.e24[fl]);
     // (rho > 1/16 -- 1-D structures, whose L2 is of the size of its own bound: the denominators are only known to be >= 1)
-    const float slope = rho <= 0.0625f ? 2.07f * (r1t * r1t) : 2.0f;
+    // (the 2.07 / (1 + t)^2 form is derived for t <= 1; t > 1 cannot pass the L2 test above with L2 <= L1, the guard states it in code)
+    const float slope = ((rho <= 0.0625f) & (t <= 1.0f)) ? 2.07f * (r1t * r1t) : 2.0f;
     const float dcoh = __builtin_fmaf(slope * t, rho, 2e-6f);
     ok &= (__builtin_fabsf(coh - Q.qc0) > dcoh) & (__builtin_fabsf(coh - Q.qc1) > dcoh);
     const int ci = (int)(Q.qc0 <= coh) + (int)(Q.qc1 <= coh);
@@ -99,6 +104,78 @@ __device__ __forceinline__ bool approx_hash(float a, float b, float d, const Has
     ok &= c_ang;                                         // (a window without any gx or gy has L2 = 0 and is never certified)
     bucket = (unsigned)((int)k * 9 + si * 3 + ci);
     return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exactly ONE-DIMENSIONAL windows ("class 1", round 6; docs/CERTIFY.md s9).  Real pictures -- above all compressed ones: 8 x 8 block
+// edges over flat ground, letterbox borders, flat graphics -- are full of windows in which every gy (or every gx) is 0.  Their
+// approximate tensor is (a', 0, 0) [or (0, 0, d')] with EXACT zeros (sums of zeros; nothing underflows, docs/CERTIFY.md s1), and then
+// the reference's tensor is (a, +-0, 0) exactly as well, |a - a'| <= eps a'.  No bound certifies such a pixel (b = 0, L2 ~ 0, xx
+// undefined: three discontinuities at once) -- on JPEG-like content they were 60-70 % of the uncertified pixels and overflowed the
+// worklist of 12-44 % of the tiles.  But the reference's hash of (a, 0, 0) is almost a constant:
+//   angle      b == 0 -> xx = 1, atan2Approximation(1e-10, 1) = a constant: the angle index of the zero tensor's bucket;
+//   strength   L1 = a/2 + sqrt14(a^2/4): the bound E_L of approx_hash applies unchanged (si, ok_str);
+//   coherence  L2 = fl(a/2 - sqrt14(fl(a a)/4)) is the table error of VRCP14(VRSQRT14(.)) at a^2/4, NOT a small number with a sign one
+//              could bound: L2 >= 0 -> sqrt(L2/L1) <= 0.0071 (AVX2 flavour: 0.0181) -> coh >= 0.985 (0.964) -> index 2;  L2 < 0 -> the
+//              reference's sqrt14(L2) is NaN -> coh NaN -> index 0 in the AVX-512 flavour ([Q <= NaN] = 0), index 2 in the AVX2 flavour
+//              (2 - [NaN <= Q0] - [NaN <= Q1]).  The AVX2 flavour's index is therefore 2 whatever the sign.
+// sign(L2) is a function of the MANTISSA of a alone (a -> 4a scales every quantity exactly by 4 or 2), so it is tabulated: c1tab[i], i =
+// mantissa >> 7 (65 536 buckets of 128 consecutive floats), bit 0 = some a of the bucket has L2 < 0, bit 1 = some has L2 >= 0, built once
+// per context by k_build_c1tab with the exact models of x86_approx_dev.h.  The pixel is certified when every bucket the box
+// [a'(1 - 1.05 eps), a'(1 + 1.05 eps)] touches (at most three) carries the same single bit -- 72 % of the class on uniformly distributed
+// mantissas (tests/test_class1.py enumerates all 2^23 mantissas against the oracle's hash and replays the bucket logic).
+// Precondition per model (device_abi.hip, configure): both coherence thresholds below 0.98 (AVX2 flavour: 0.96).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kC1Buckets = 65536u;
+__global__ __launch_bounds__(256) void k_build_c1tab(const uint2* __restrict__ tab14, uint8_t* __restrict__ out)
+{
+    __shared__ uint2 sT[128];
+    if (threadIdx.x < 128) sT[threadIdx.x] = tab14[threadIdx.x];
+    __syncthreads();
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    unsigned flags = 0u;
+    for (unsigned k = 0; k < 128u; k++) {
+        // the reference's own operations on the tensor (a, 0, 0) (Raisr_AVX512.cpp:185-202), a in [1, 2)
+        const float a = __uint_as_float(0x3f800000u | (i << 7) | k), b = 0.0f, d = 0.0f;
+        const float T = a + d;
+        const float Dt = (a * d) - (b * b);
+        const float rad = ((T * T) / 4.0f) - Dt;
+        const float s = x86dev::rcp14(x86dev::rsqrt14(rad, sT + 64), sT);
+        const float L2 = (T / 2.0f) - s;
+        flags |= (L2 < 0.0f) ? 1u : 2u;
+    }
+    out[i] = (uint8_t)flags;
+}
+
+// class-1 decision of one pixel: a1 = the non-zero diagonal entry of its approximate tensor.  Returns whether the AVX-512 flavour's
+// coherence index is certain and writes it to ci0 (the AVX2 flavour's is 2).
+__device__ __forceinline__ bool class1_coherence(float a1, const SepW& S, const uint8_t* __restrict__ c1tab, unsigned& ci0)
+{
+    const float e = S.c1e * a1;
+    const unsigned lo = __float_as_uint(a1 - e), hi = __float_as_uint(a1 + e);
+    const unsigned il = (lo >> 7) & (kC1Buckets - 1u), ih = (hi >> 7) & (kC1Buckets - 1u);
+    const unsigned span = (ih - il) & (kC1Buckets - 1u);                  // cyclic: the box may straddle a power of two (mantissa wraps)
+    const unsigned im = span >= 2u ? (il + 1u) & (kC1Buckets - 1u) : il;
+    const unsigned t = (unsigned)c1tab[il] | (unsigned)c1tab[im] | (unsigned)c1tab[ih];
+    ci0 = t == 1u ? 0u : 2u;
+    // magnitudes for which a^2 / 4 and L2 are normal numbers and the scale invariance holds (content: 4.5e-15 <= a <~ 1)
+    return (span <= 2u) & ((t == 1u) | (t == 2u)) & (a1 > 1e-17f) & (a1 < 1e17f);
+}
+
+// first (bA) / second (bB) hash of a class-1 pixel in a column that hashes with the AVX-512 flavour (inA) and / or the AVX2 flavour (inB);
+// si / ok_str: strength index and "preconditions + strength certified" of approx_hash.  Returns whether the pixel is certified.
+__device__ __forceinline__ bool class1_buckets(float a1, unsigned si, bool ok_str, const SepW& S, const PassParams& P, bool inA, bool inB,
+                                               unsigned& bA, unsigned& bB)
+{
+    unsigned ci0;
+    const bool ci_ok = class1_coherence(a1, S, P.c1tab, ci0);
+    const unsigned b0 = (unsigned)(P.zero_bucket[0] / 9) * 9u + si * 3u + ci0;      // AVX-512 flavour: the zero tensor's angle index (b == 0)
+    const unsigned b1 = (unsigned)(P.zero_bucket[1] / 9) * 9u + si * 3u + 2u;       // AVX2 flavour
+    const bool okA = inA ? (ci_ok && (P.c1_ok & 1)) : true;                          // the flavours this column hashes with
+    const bool okB = inB ? (P.c1_ok & 2) != 0 : true;
+    bA = inA ? b0 : b1;
+    bB = b1;
+    return ok_str && okA && okB;
 }
 
 // first / second hash of a pixel in column c from its exact tensor: the flavour logic of hash_phase's epilogue
@@ -268,24 +345,50 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     const int fl = inB ? 1 : 0;                            // the AVX2 flavour's wider table error covers the re-hashed columns too
     const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
     unsigned nUnc = 0, certbits = 0;
+    unsigned bkA[RPW], bkB[RPW];                           // first / second hash candidates of the lane's pixels
+    unsigned c1bits = 0, okbits = 0, sibits = 0;
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
-        const int prow = RPW * w + j;
-        const int r = r0 + prow;
-        const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
         unsigned bucket;
-        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket);
+        int si;
+        bool ok_str;
+        bool cert = approx_hash(ta[j], tb[j], td[j], Q, S, fl, bucket, &si, &ok_str);
         const bool zero = (ta[j] + td[j]) == 0.0f;          // flat window: the reference's tensor is exactly (0, 0, 0) as well
         cert |= zero;
         // first hash: AVX-512 flavour where the column has one, else the AVX2 flavour; second hash: AVX2 flavour of the
         // re-hashed columns.  A certified bucket holds for both flavours (fl selects the wider table error there); the
         // zero tensor's bucket is looked up per flavour (computed once per tile with the exact code).
-        const unsigned bA = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
-        const unsigned bB = zero ? (unsigned)P.zero_bucket[1] : bucket;
-        const bool unc = zone && (!cert || P.cert_check);
-        sH[prow * TW + lane] = zone ? (uint8_t)bA : (uint8_t)0xFFu;
-        sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bB : (uint8_t)0xFFu;
+        bkA[j] = zero ? (unsigned)P.zero_bucket[inA ? 0 : 1] : bucket;
+        bkB[j] = zero ? (unsigned)P.zero_bucket[1] : bucket;
         certbits |= (cert ? 1u : 0u) << j;
+        // exactly one-dimensional window (class 1 above): decided below, outside this straight-line code
+        const bool c1 = !zero && tb[j] == 0.0f && (ta[j] == 0.0f || td[j] == 0.0f);
+        c1bits |= (c1 ? 1u : 0u) << j;
+        okbits |= (ok_str ? 1u : 0u) << j;
+        sibits |= (unsigned)si << (2 * j);
+    }
+    if (P.c1tab && __any(c1bits != 0u)) {                  // wave-uniform: natural content rarely enters
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            if ((c1bits >> j) & 1u) {
+                unsigned bA, bB;
+                if (class1_buckets(fmaxf(ta[j], td[j]), (sibits >> (2 * j)) & 3u, (okbits >> j) & 1u, S, P, inA, inB, bA, bB)) {
+                    bkA[j] = bA;
+                    bkB[j] = bB;
+                    certbits |= 1u << j;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+        const int prow = RPW * w + j;
+        const int r = r0 + prow;
+        const bool zone = r < P.H - kMargin && c < P.c_final && (inA || inB);
+        const bool cert = (certbits >> j) & 1u;
+        const bool unc = zone && (!cert || P.cert_check);
+        sH[prow * TW + lane] = zone ? (uint8_t)bkA[j] : (uint8_t)0xFFu;
+        sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)bkB[j] : (uint8_t)0xFFu;
         if (unc) {
             const unsigned slot = atomicAdd(sCnt, 1u);
             if (slot < kListMax) sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
@@ -452,8 +555,14 @@ __global__ __launch_bounds__(256) void k_debug_approx_hash(const float* __restri
     const HashQf Q = {P.qangle, P.qs0, P.qs1, P.qc0, P.qc1};
     const float a = abd[3 * (size_t)i], b = abd[3 * (size_t)i + 1], d = abd[3 * (size_t)i + 2];
     unsigned bucket;
-    bool cert = approx_hash(a, b, d, Q, S, fl, bucket);
+    int si;
+    bool ok_str;
+    bool cert = approx_hash(a, b, d, Q, S, fl, bucket, &si, &ok_str);
     if ((a + d) == 0.0f) { cert = true; bucket = (unsigned)P.zero_bucket[fl]; }
+    else if (P.c1tab && b == 0.0f && (a == 0.0f || d == 0.0f)) {        // exactly one-dimensional window: the class-1 rule, as in hash_phase_ac
+        unsigned bA, bB;
+        if (class1_buckets(fmaxf(a, d), (unsigned)si, ok_str, S, P, fl == 0, fl == 1, bA, bB)) { cert = true; bucket = bA; }
+    }
     bucket_out[i] = (uint8_t)bucket;
     cert_out[i] = cert ? 1 : 0;
 }

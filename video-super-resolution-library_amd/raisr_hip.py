@@ -149,6 +149,8 @@ def _load(path):
         L.RNLHandler_HostFree.argtypes = [ctypes.c_void_p]
         L.RNLHandler_HostFree.restype = None
         L.raisr_hip_packed_frame_layout.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+        if hasattr(L, "raisr_hip_debug_read_c1tab"):
+            L.raisr_hip_debug_read_c1tab.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         if hasattr(L, "raisr_hip_debug_approx_hash"):
             L.raisr_hip_debug_approx_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -522,15 +524,24 @@ class RaisrDevice:
     def fast(self):
         return int(self._L.raisr_hip_get_fast(self._h))
 
+    def read_c1tab(self):
+        """The class-1 sign table of the certified hash stage as this context built it (65 536 bytes; docs/CERTIFY.md s9)."""
+        out = np.zeros(65536, np.uint8)
+        self._check(self._hook("raisr_hip_debug_read_c1tab")(self._h, out.ctypes.data), "debug_read_c1tab")
+        return out
+
     def certify_debug(self, collect=True, check=False):
         """Certified hash stage: start (and zero) / stop the statistics; check=True also runs the exact path for every pixel."""
         self._check(self._hook("raisr_hip_debug_certify")(self._h, int(collect), int(check)), "debug_certify")
 
     def certify_stats(self):
-        """dict(uncertain, mismatches, pixels) accumulated since certify_debug(True, ...)."""
-        out = (ctypes.c_uint * 3)()
+        """dict(uncertain, mismatches, pixels; tiles_listed, tiles_overflow, tiles, tiles_flat) accumulated since certify_debug(True, ...).
+        The tile counters describe the worklist (tiles with a non-empty list / whose list overflowed into the all-exact stage): read them
+        from a run WITHOUT the self-check, which lists every pixel."""
+        out = (ctypes.c_uint * 8)()
         self._check(self._hook("raisr_hip_debug_certify_stats")(self._h, out), "debug_certify_stats")
-        return {"uncertain": int(out[0]), "mismatches": int(out[1]), "pixels": int(out[2])}
+        return {"uncertain": int(out[0]), "mismatches": int(out[1]), "pixels": int(out[2]),
+                "tiles_listed": int(out[3]), "tiles_overflow": int(out[4]), "tiles": int(out[5]), "tiles_flat": int(out[6])}
 
     def timing_enable(self, on=True):
         self._check(self._L.raisr_hip_kernel_timing_enable(self._h, int(on)), "kernel_timing_enable")
