@@ -91,8 +91,10 @@ int    raisr_hip_set_model_blob_device(raisr_hip_ctx *ctx, int pass_index, const
  * library and has no counterpart; bench.py / sharding.py issue the same broadcast through torch.distributed. */
 int    raisr_hip_broadcast_model_blob(void *nccl_comm, int root, void *device_blob, size_t bytes, void *stream);
 /* One process, several GPUs (raisr_hip_stream_create_multi): blobs[0] (on devices[0]) holds the packed model, blobs[i] (on
- * devices[i]) receives it -- one in-process RCCL communicator per device and a grouped broadcast over xGMI when the devices are
- * distinct, device / peer copies when a device is listed twice, RAISR_HIP_NO_RCCL=1 is set or librccl is absent.  Synchronous. */
+ * devices[i]) receives it.  Default: n - 1 concurrent peer copies out of devices[0] (xGMI is a full mesh of point-to-point links: the
+ * copies to different GPUs run on different links at once; peer access is enabled where the runtime grants it).  RAISR_HIP_RCCL=1 opts
+ * into the in-process RCCL path instead (one communicator set per device list, created once per process, grouped ncclBroadcast) --
+ * EXPERIMENTAL: it has never run with more than one rank.  RAISR_HIP_NO_RCCL=1 forces the copies.  Synchronous. */
 int    raisr_hip_broadcast_model_blob_devices(const int *devices, int n, void *const *device_blobs, size_t bytes);
 
 /* Geometry / resources ------------------------------------------------------------------------ */

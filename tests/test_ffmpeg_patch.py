@@ -40,7 +40,8 @@ def test_filter_diff_applies_and_the_result_compiles_against_our_headers(tmp_pat
                    ".request_frame = request_frame", "ret == AVERROR_EOF && raisr->q_count > 0", "collect_oldest(ctx, 0)"):
         assert needle in src, needle
     # devices=0,1,..|all: the ring spans several GPUs, the filter keeps async frames in flight on each
-    for needle in ('{"devices",', "RNLHandler_SetDeviceList(raisr->devices)", "RNLHandler_AsyncCapacity()", "raisr->q_count == raisr->q_cap"):
+    for needle in ('{"devices",', "RNLHandler_SetDeviceList(raisr->devices)", "RNLHandler_AsyncCapacity()", "raisr->q_count == raisr->q_cap",
+                   "raisr->async > 0 && raisr->q_cap < 1", "if (raisr->q_count <= 0)"):   # (round 6: no capacity is an init error; an empty queue is never collected from)
         assert needle in src, needle
     # pinned=1: input and output frames from buffer pools over the library's page-locked allocator (the buffer owns the memory:
     # nothing is page-locked behind FFmpeg's back, nothing outlives its buffer)

@@ -128,14 +128,38 @@ def test_plugin_api_ring_over_a_device_list(how, monkeypatch):
             assert np.array_equal(outs[done][0], refs[done]), done
             done += 1; inflight -= 1
         assert done == n
-        assert R.RNLHandler_SetDeviceList("") == 0                                                # no list: RAISR_HIP_DEVICES if set, else the single device
-        cap = 4 if how == "env" else 2
+        assert R.RNLHandler_SetDeviceList("") == 0                                                # an explicit empty list = the single device again, whatever
+        cap = 2                                                                                   # RAISR_HIP_DEVICES says (include/raisr/RaisrHandler.h)
+        assert R.RNLHandler_AsyncCapacity() == cap
         for k in range(cap):
             assert R.RNLHandler_Submit((ys[k], us[k], us[k]), outs[k]) == 0
         assert R.RNLHandler_Submit((ys[cap], us[cap], us[cap]), outs[cap]) == R.RNLErrorInsufficientResources
         for k in range(cap):
             assert R.RNLHandler_Collect() == 0
             assert np.array_equal(outs[k][0], refs[k]), k
+    finally:
+        assert R.RNLHandler_Deinit() == 0
+
+
+def test_malformed_device_environment_is_an_error_at_set_async_depth(monkeypatch):
+    """RAISR_HIP_DEVICES that is not a device list: RNLHandler_SetAsyncDepth(n > 0) refuses (with the library's message) instead of
+    reporting a capacity of 0 that a caller would divide its queue by; an explicit RNLHandler_SetDeviceList overrides the variable."""
+    import raisr_hip as R
+    import synth
+    w, h = 176, 100
+    y = synth.natural_y(w, h, 8, seed=1); u = synth.chroma(w // 2, h // 2, 8)
+    out = (np.zeros((2 * h, 2 * w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8))
+    monkeypatch.setenv("RAISR_HIP_DEVICES", "0;x")
+    assert R.RNLHandler_SetOpenCLContext(0, 0) == 0
+    assert R.RNLHandler_Init(folder("filters_2x/filters_highres"), 2.0, 8, R.VideoRange, 20, R.AVX512, 1, 1) == 0
+    try:
+        assert R.RNLHandler_SetRes((y, u, u), out) == 0
+        assert R.RNLHandler_SetAsyncDepth(2) == R.RNLErrorBadParameter
+        assert R.RNLHandler_AsyncCapacity() == 0
+        assert R.RNLHandler_SetAsyncDepth(0) == 0                                                 # switching the ring off never consults the list
+        assert R.RNLHandler_SetDeviceList("0") == 0
+        assert R.RNLHandler_SetAsyncDepth(2) == 0 and R.RNLHandler_AsyncCapacity() == 2
+        assert R.RNLHandler_Submit((y, u, u), out) == 0 and R.RNLHandler_Collect() == 0
     finally:
         assert R.RNLHandler_Deinit() == 0
 
@@ -159,9 +183,9 @@ def test_blob_broadcast_over_a_device_list_copies_the_blob():
 
 
 def test_in_process_rccl_broadcast_with_one_rank(monkeypatch):
-    """The RCCL leg of raisr_hip_broadcast_model_blob_devices (ncclCommInitAll, grouped ncclBroadcast, ncclCommDestroy through the
-    dlopen'ed librccl) needs distinct devices; a one-GPU box can run it with ONE rank only (RAISR_HIP_FORCE_RCCL=1): the symbols
-    resolve, the communicator comes up and goes away, the root's blob is untouched."""
+    """The opt-in RCCL leg of raisr_hip_broadcast_model_blob_devices (ncclCommInitAll once per device list, grouped ncclBroadcast through
+    the dlopen'ed librccl) needs distinct devices; a one-GPU box can run it with ONE rank only (RAISR_HIP_FORCE_RCCL=1): the symbols
+    resolve, the communicator comes up, a second broadcast (the model's second pass) REUSES it, the root's blob is untouched."""
     import raisr_hip as R
     import torch
     monkeypatch.setenv("RAISR_HIP_FORCE_RCCL", "1")
@@ -171,6 +195,33 @@ def test_in_process_rccl_broadcast_with_one_rank(monkeypatch):
     keep = src.clone()
     devs = (ctypes.c_int * 1)(0)
     ptrs = (ctypes.c_void_p * 1)(src.data_ptr())
-    assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 1, ptrs, blob.size) == 0, R.last_error()
+    for _ in range(3):
+        assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, 1, ptrs, blob.size) == 0, R.last_error()
     torch.cuda.synchronize()
     assert torch.equal(src, keep)
+
+
+@pytest.mark.parametrize("rccl", [False, True], ids=["peer-copies", "in-process-rccl"])
+def test_blob_broadcast_over_distinct_devices(monkeypatch, rccl):
+    """Two or more GPUs (skipped on the one-GPU boxes of rounds 1-6): the default hand-over -- concurrent peer copies out of devices[0] --
+    and the opt-in in-process RCCL broadcast both leave every device with the source's bytes, twice in a row (pass 1, pass 2)."""
+    import raisr_hip as R
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    if rccl:
+        monkeypatch.setenv("RAISR_HIP_RCCL", "1")
+    bank, qstr, qcoh, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, 1)
+    blob = R.pack_model_blob(bank, qstr, qcoh, qa)
+    src = torch.from_numpy(blob).to("cuda:0")
+    dsts = [torch.zeros(blob.size, dtype=torch.uint8, device=f"cuda:{i}") for i in range(1, n)]
+    devs = (ctypes.c_int * n)(*range(n))
+    ptrs = (ctypes.c_void_p * n)(src.data_ptr(), *[d.data_ptr() for d in dsts])
+    for rep in range(2):
+        for d in dsts:
+            d.zero_()
+        torch.cuda.synchronize()
+        assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, n, ptrs, blob.size) == 0, R.last_error()
+        for d in dsts:
+            assert torch.equal(d.cpu(), src.cpu()), rep

@@ -39,6 +39,7 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../../include/raisr_hip.h"
@@ -1125,71 +1126,106 @@ int raisr_hip_broadcast_model_blob(void* nccl_comm, int root, void* device_blob,
 }
 
 // In-process counterpart for ONE host process driving several GPUs (raisr_hip_stream_create_multi): blobs[0] on devices[0]
-// holds the packed model; blobs[i] on devices[i] receives it.  Distinct devices: one RCCL communicator per device
-// (ncclCommInitAll) and a grouped ncclBroadcast -- the filter bank crosses xGMI once per device and never the PCIe bus again.
-// A device listed more than once (one GPU standing in for several: tests, oversubscription), RAISR_HIP_NO_RCCL=1 or a missing
-// librccl: plain device / peer copies.
+// holds the packed model; blobs[i] on devices[i] receives it (raisr_hip_broadcast_model_blob_devices below).
+// In-process RCCL (opt-in, RAISR_HIP_RCCL=1): librccl is dlopen'ed on first use; ONE communicator set per device list, created on first use
+// and kept for the life of the process (both passes of a model and every later model reuse it; round 5 created and destroyed one per pass).
+namespace {
+struct RcclApi {
+    typedef int (*initall_fn)(void**, int, const int*);
+    typedef int (*group_fn)(void);
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    initall_fn initall = nullptr; group_fn gstart = nullptr, gend = nullptr; bcast_fn bcast = nullptr;
+    bool tried = false;
+    std::map<std::vector<int>, std::vector<void*>> comms;     // device list -> communicators (never destroyed: RCCL's teardown at exit is not worth a hang)
+    std::mutex mu;
+};
+RcclApi* rccl_api() { static RcclApi* a = new RcclApi; return a; }
+
+// 0 = broadcast done, 1 = RCCL not available for this list (caller copies), -1 = RCCL failed mid-way
+int rccl_broadcast_in_process(const int* devices, int n, void* const* blobs, size_t bytes)
+{
+    RcclApi& A = *rccl_api();
+    std::lock_guard<std::mutex> lk(A.mu);
+    if (!A.tried) {
+        A.tried = true;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            A.gstart = reinterpret_cast<RcclApi::group_fn>(dlsym(h, "ncclGroupStart"));
+            A.gend = reinterpret_cast<RcclApi::group_fn>(dlsym(h, "ncclGroupEnd"));
+            A.bcast = reinterpret_cast<RcclApi::bcast_fn>(dlsym(h, "ncclBroadcast"));
+            A.initall = reinterpret_cast<RcclApi::initall_fn>(dlsym(h, "ncclCommInitAll"));
+            if (!A.gstart || !A.gend || !A.bcast) A.initall = nullptr;
+        }
+    }
+    if (!A.initall) return 1;
+    const std::vector<int> key(devices, devices + n);
+    auto it = A.comms.find(key);
+    if (it == A.comms.end()) {
+        std::vector<void*> cm((size_t)n, nullptr);
+        if (A.initall(cm.data(), n, devices) != 0) { (void)hipGetLastError(); return 1; }      // no communicator: copies
+        it = A.comms.emplace(key, cm).first;
+    }
+    const std::vector<void*>& comms = it->second;
+    const int kNcclUint8 = 1;
+    bool ok = A.gstart() == 0;
+    for (int i = 0; i < n && ok; i++)
+        ok = hipSetDevice(devices[i]) == hipSuccess && A.bcast(blobs[i], blobs[i], bytes, kNcclUint8, 0, comms[(size_t)i], (hipStream_t) nullptr) == 0;
+    ok = (A.gend() == 0) && ok;
+    for (int i = 0; i < n; i++) if (hipSetDevice(devices[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) ok = false;
+    return ok ? 0 : -1;
+}
+}  // namespace
+
+// Hand the model blob that sits on devices[0] (blobs[0]) to the other devices of a one-process ring.
+// DEFAULT (round 6): n - 1 concurrent peer copies out of devices[0].  xGMI on an MI355X node is a full mesh of point-to-point links, so the
+// copies to different GPUs travel on different links at the same time -- for one 664 KB blob that is the optimal broadcast, a ring
+// collective would serialise hops for nothing; peer access is switched on where the runtime grants it (else the runtime stages through
+// the host, still correct).  The in-process RCCL broadcast (ncclCommInitAll + grouped ncclBroadcast from one thread) is OPT-IN with
+// RAISR_HIP_RCCL=1: it has only ever run with one rank (no second GPU in any build or test box so far), and a hang inside it would
+// stop every multi-GPU Submit at model load.  RAISR_HIP_NO_RCCL=1 still forces the copies; RAISR_HIP_FORCE_RCCL=1 (tests) sends even a
+// single device through the communicator.  The one-process-per-GPU launch (bench.py --gpus N, sharding.py) broadcasts with RCCL through
+// torch.distributed as before.
 int raisr_hip_broadcast_model_blob_devices(const int* devices, int n, void* const* blobs, size_t bytes)
 {
     if (!devices || !blobs || n < 1 || bytes < (size_t)kBlobHeader) return fail(RAISR_HIP_EINVAL, "bad argument");
     for (int i = 0; i < n; i++) if (!blobs[i] || devices[i] < 0) return fail(RAISR_HIP_EINVAL, "bad argument");
-    // RAISR_HIP_FORCE_RCCL=1 (tests): also a single device goes through the communicator -- the call sequence of the n-device case with one
-    // rank, which is all a one-GPU box can execute of it
     const char* force = getenv("RAISR_HIP_FORCE_RCCL");
-    if (n == 1 && !(force && atoi(force) != 0)) return RAISR_HIP_OK;
+    const bool forced = force && atoi(force) != 0;
+    if (n == 1 && !forced) return RAISR_HIP_OK;
     bool distinct = true;
     for (int i = 0; i < n && distinct; i++)
         for (int k = 0; k < i; k++) if (devices[k] == devices[i]) { distinct = false; break; }
     const char* no = getenv("RAISR_HIP_NO_RCCL");
-    bool done = false;
-    if (distinct && !(no && atoi(no) != 0)) {
-        typedef int (*initall_fn)(void**, int, const int*);
-        typedef int (*group_fn)(void);
-        typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-        typedef int (*destroy_fn)(void*);
-        static std::mutex mu;
-        static initall_fn initall = nullptr; static group_fn gstart = nullptr, gend = nullptr; static bcast_fn bcast = nullptr; static destroy_fn destroy = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!initall) {
-                void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-                if (h) {
-                    gstart = reinterpret_cast<group_fn>(dlsym(h, "ncclGroupStart"));
-                    gend = reinterpret_cast<group_fn>(dlsym(h, "ncclGroupEnd"));
-                    bcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
-                    destroy = reinterpret_cast<destroy_fn>(dlsym(h, "ncclCommDestroy"));
-                    initall = reinterpret_cast<initall_fn>(dlsym(h, "ncclCommInitAll"));
-                    if (!gstart || !gend || !bcast || !destroy) initall = nullptr;
-                }
-            }
-        }
-        if (initall) {
-            std::vector<void*> comms((size_t)n, nullptr);
-            if (initall(comms.data(), n, devices) == 0) {
-                const int kNcclUint8 = 1;
-                bool ok = gstart() == 0;
-                for (int i = 0; i < n && ok; i++) {
-                    ok = hipSetDevice(devices[i]) == hipSuccess &&
-                         bcast(blobs[i], blobs[i], bytes, kNcclUint8, 0, comms[(size_t)i], (hipStream_t) nullptr) == 0;
-                }
-                ok = (gend() == 0) && ok;
-                for (int i = 0; i < n; i++) { if (hipSetDevice(devices[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) ok = false; }
-                for (void* cm : comms) if (cm) (void)destroy(cm);
-                if (!ok) return fail(RAISR_HIP_ERUNTIME, "in-process RCCL broadcast of the model blob failed");
-                done = true;
-            } else (void)hipGetLastError();                      // no communicator (e.g. one visible GPU under a restrictive runtime): copies below
-        }
+    const char* want = getenv("RAISR_HIP_RCCL");
+    if (distinct && (forced || (want && atoi(want) != 0)) && !(no && atoi(no) != 0)) {
+        const int r = rccl_broadcast_in_process(devices, n, blobs, bytes);
+        if (r == 0) return RAISR_HIP_OK;
+        if (r < 0) return fail(RAISR_HIP_ERUNTIME, "in-process RCCL broadcast of the model blob failed");
     }
-    if (!done) {
-        for (int i = 1; i < n; i++) {
-            if (blobs[i] == blobs[0]) continue;
-            if (devices[i] == devices[0]) { HIP_TRY(hipSetDevice(devices[0])); HIP_TRY(hipMemcpy(blobs[i], blobs[0], bytes, hipMemcpyDeviceToDevice)); }
-            else HIP_TRY(hipMemcpyPeer(blobs[i], devices[i], blobs[0], devices[0], bytes));
+    // peer copies out of devices[0], all in flight together (one per destination device, on that device's null stream)
+    HIP_TRY(hipSetDevice(devices[0]));
+    HIP_TRY(hipDeviceSynchronize());                                     // blobs[0] is complete
+    for (int i = 1; i < n; i++) {
+        if (blobs[i] == blobs[0]) continue;
+        if (devices[i] == devices[0]) { HIP_TRY(hipSetDevice(devices[0])); HIP_TRY(hipMemcpyAsync(blobs[i], blobs[0], bytes, hipMemcpyDeviceToDevice, nullptr)); continue; }
+        HIP_TRY(hipSetDevice(devices[i]));
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();    // staged copies then
+            else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
         }
-        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipMemcpyPeerAsync(blobs[i], devices[i], blobs[0], devices[0], bytes, nullptr));
+    }
+    for (int i = 0; i < n; i++) {                                        // both ends of every copy
+        bool seen = false;
+        for (int k = 0; k < i; k++) if (devices[k] == devices[i]) seen = true;
+        if (seen) continue;
+        HIP_TRY(hipSetDevice(devices[i]));
         HIP_TRY(hipDeviceSynchronize());
     }
+    HIP_TRY(hipSetDevice(devices[0]));
     return RAISR_HIP_OK;
 }
 

@@ -58,7 +58,8 @@ struct State {
     raisr_hip_stream *ring = nullptr;
     unsigned asyncDepth = 0;                      // RNLHandler_SetAsyncDepth; 0 = no ring
     bool deviceChosen = false;                    // RNLSetOpenCLContext named a device; otherwise RAISR_HIP_DEVICE / 0
-    std::vector<int> devices;                     // RNLSetDeviceList: GPUs of the asynchronous ring (empty: RAISR_HIP_DEVICES, else the one device)
+    std::vector<int> devices;                     // RNLSetDeviceList: GPUs of the asynchronous ring
+    bool devicesSet = false;                      // RNLSetDeviceList was called: its list ("" = the handler's one device) wins over RAISR_HIP_DEVICES
     bool external = false;                        // asm = HIPExternal: plane pointers are device pointers
     void *externalStream = nullptr;               // caller's hipStream_t for external frames (NULL: own stream + wait)
 } G;
@@ -648,6 +649,7 @@ RNLERRORTYPE RNLDeinit()
     G.device = 0;
     G.asyncDepth = 0;
     G.devices.clear();
+    G.devicesSet = false;
     gPins.clear();
     return RNLErrorNone;
 }
@@ -665,10 +667,16 @@ void RNLHostFree(void *p) { raisr_hip_host_free(p); }
 // RNLSubmit enqueues a frame on the next lane of a ring (upload, kernels, download: all asynchronous on page-locked planes) and
 // returns; RNLCollect waits for the OLDEST submitted frame.  Same validation and the same bits as RNLProcess; the caller keeps
 // every plane valid and untouched between a frame's Submit and its Collect.
+static bool ringDevices(std::vector<int> &devs);
+
 RNLERRORTYPE RNLSetAsyncDepth(unsigned int depth)
 {
     if (depth > RAISR_HIP_STREAM_MAX_DEPTH) return RNLErrorBadParameter;           // what the ring builds; a larger request is refused, not clamped
     if (G.ring && raisr_hip_stream_in_flight(G.ring) > 0) return RNLErrorBadParameter;      // collect first
+    if (depth) {            // a malformed RAISR_HIP_DEVICES is an error HERE (with its message), not a capacity of 0 later
+        std::vector<int> devs;
+        if (!ringDevices(devs)) return RNLErrorBadParameter;
+    }
     dropRing();
     G.asyncDepth = depth;
     return RNLErrorNone;
@@ -683,14 +691,16 @@ RNLERRORTYPE RNLSetDeviceList(const char *devices)
     if (n < 0) return RNLErrorBadParameter;
     dropRing();
     G.devices.assign(list, list + n);
+    G.devicesSet = true;
     return RNLErrorNone;
 }
 
-// the ring's GPUs: RNLSetDeviceList, else RAISR_HIP_DEVICES, else the handler's one device; false: RAISR_HIP_DEVICES is malformed
+// the ring's GPUs: RNLSetDeviceList (an empty list there = the handler's one device, whatever the environment says), else
+// RAISR_HIP_DEVICES, else the handler's one device; false: RAISR_HIP_DEVICES is malformed
 static bool ringDevices(std::vector<int> &devs)
 {
     devs = G.devices;
-    if (devs.empty()) {
+    if (devs.empty() && !G.devicesSet) {
         if (const char *e = std::getenv("RAISR_HIP_DEVICES")) {
             int list[RAISR_HIP_STREAM_MAX_DEVICES];
             const int n = raisr_hip_parse_device_list(e, list, RAISR_HIP_STREAM_MAX_DEVICES);
