@@ -23,6 +23,8 @@ and, at N = 1 (outside the timed region of `value`, never mixed into it):
                   and `pageable_planes` for ordinary malloc'ed ones
   stream       -- host planes -> host planes through the library's pinned-ring batch entry (uploads, kernels and
                   downloads of neighbouring frames overlapped)
+  stream_single_process -- the same through the ONE-process multi-device ring with this GPU listed twice (2 slots x 2 lanes): the
+                  per-slot cost of the code path `--single-process --gpus N` takes on N GPUs
   parity       -- one frame of the workload against the CPU oracle: mismatching pixels and PSNR; `certify` = the certified
                   hash stage's self-check over every benchmarked frame
   configs      -- BASELINE.json's C1, C3, C4, C5 next to C2, plus C2b = the configuration the reference publishes its numbers on
@@ -863,6 +865,16 @@ def main():
                 leg("end_to_end", lambda: end_to_end_leg(R, wl, args.extra_frames, gpu))
             if hasattr(R, "RaisrStream"):
                 leg("stream", lambda: stream_leg(R, wl, gpu, args.extra_frames, blobs=blobs))
+
+                def ring_two_slots():
+                    # the ONE-PROCESS multi-device ring (raisr_hip_stream_create_multi, what --single-process times on N GPUs) with this GPU
+                    # listed twice: two device slots x 2 lanes = the same four frames in flight as `stream`, through the multi-device code
+                    # path (frame i -> slot i mod 2, the model handed from slot 0 to slot 1 inside the library).  Next to `stream` it is the
+                    # ring's per-slot cost -- the only part of the multi-GPU host path one GPU can measure.
+                    r = stream_leg(R, wl, [gpu, gpu], args.extra_frames, lanes_per_device=2)
+                    r["what"] += "; the same physical GPU listed twice (plumbing cost of the multi-device ring, not a scaling figure)"
+                    return r
+                leg("stream_single_process", ring_two_slots)
             def parity_all():
                 par = parity_leg(R, wl, gpu, blobs, args.frame_kind)
                 par["certify"] = certify_leg(R, wl, gpu, blobs, host_frames)        # self-check over every frame that was benchmarked

@@ -31,6 +31,10 @@ int raisr_hip_debug_read_stage(raisr_hip_ctx *ctx, int pass_index, uint8_t *hash
  * Replaces nothing in the reference; it is the observability of an optimisation the reference does not have. */
 int raisr_hip_debug_certify(raisr_hip_ctx *ctx, int collect, int check);
 int raisr_hip_debug_certify_stats(raisr_hip_ctx *ctx, unsigned out[8]);
+/* Multi-device ring, model hand-over (raisr_hip_stream_set_model with more than one device slot): number of per-device staging blobs
+ * currently allocated.  With RAISR_HIP_TEST_FAIL_BLOB_SLOT=k in the environment the allocation on slot k fails (fault injection): the
+ * call must return RAISR_HIP_ENOMEM and leave this count at 0 -- nothing of slots 0..k-1 stays behind. */
+int raisr_hip_debug_stream_live_blobs(void);
 /* Class-1 sign table of the certified hash stage (exactly one-dimensional windows, docs/CERTIFY.md s9): 65 536 bytes, entry i = the floats
  * whose mantissa >> 7 is i; bit 0: some a of them has fl(a/2 - VRCP14(VRSQRT14(fl(a a)/4))) < 0, bit 1: some has it >= 0.
  * RAISR_HIP_ESTATE when the class is switched off (RAISR_HIP_C1=0 at context creation). */

@@ -225,3 +225,30 @@ def test_blob_broadcast_over_distinct_devices(monkeypatch, rccl):
         assert R.lib().raisr_hip_broadcast_model_blob_devices(devs, n, ptrs, blob.size) == 0, R.last_error()
         for d in dsts:
             assert torch.equal(d.cpu(), src.cpu()), rep
+
+
+def test_failed_blob_allocation_on_slot_k_releases_the_earlier_slots(monkeypatch):
+    """raisr_hip_stream_set_model over several device slots allocates one staging blob per slot; when slot k cannot get one, the call
+    returns ENOMEM and slots 0..k-1 are freed again (fault injection of the test-hooks flavour: RAISR_HIP_TEST_FAIL_BLOB_SLOT).  The ring
+    stays usable: the same call without the fault succeeds and frames come out right."""
+    import raisr_hip as R
+    import synth
+    L = R.lib_hooks()
+    L.raisr_hip_debug_stream_live_blobs.restype = ctypes.c_int
+    bank, qstr, qcoh, qa = R.read_model_folder(folder("filters_2x/filters_highres"), 8, 1)
+    bank = np.ascontiguousarray(bank, np.float32); qstr = np.ascontiguousarray(qstr, np.float64); qcoh = np.ascontiguousarray(qcoh, np.float64)
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 3)(0, 0, 0)
+    assert L.raisr_hip_stream_create_multi(ctypes.byref(h), devs, 3, 1) == 0
+    try:
+        args = (h, 0, bank.ctypes.data, bank.shape[0], bank.shape[1], qstr.ctypes.data, qcoh.ctypes.data, qa)
+        assert L.raisr_hip_debug_stream_live_blobs() == 0
+        for k in (0, 1, 2):
+            monkeypatch.setenv("RAISR_HIP_TEST_FAIL_BLOB_SLOT", str(k))
+            assert L.raisr_hip_stream_set_model(*args) == -3                                      # RAISR_HIP_ENOMEM (include/raisr_hip.h)
+            assert L.raisr_hip_debug_stream_live_blobs() == 0, k
+        monkeypatch.delenv("RAISR_HIP_TEST_FAIL_BLOB_SLOT")
+        assert L.raisr_hip_stream_set_model(*args) == 0
+        assert L.raisr_hip_debug_stream_live_blobs() == 0
+    finally:
+        L.raisr_hip_stream_destroy(h)

@@ -297,6 +297,7 @@ struct raisr_hip_ctx {
     // device staging for raisr_hip_process_host
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
     HostBounce bounce;                          // page-locked bounce memory for pageable host planes (host_copy.h)
+    int numa_node = -1;                         // NUMA node of the device's PCI function (-1: unknown / single node): which row-copy pool serves this context
     hipEvent_t ev_chroma = nullptr;             // chroma lane done (packed-frame download waits for it)
     KernelTimer timer;
 };
@@ -895,6 +896,12 @@ int raisr_hip_create(raisr_hip_ctx** out, int device_index)
     HIP_TRY(hipSetDevice(device_index));
     raisr_hip_ctx* c = new raisr_hip_ctx();
     c->device = device_index;
+    {   // NUMA node of the device (several-node hosts only): its row-copy pool runs on that node's CPUs (host_copy.h, raisr_numa)
+        char bdf[32] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device_index) == hipSuccess) c->numa_node = raisr_numa::node_for_device(bdf);
+        else (void)hipGetLastError();
+        c->bounce.node = c->numa_node;
+    }
     const int rc = create_impl(c);
     if (rc != RAISR_HIP_OK) { const std::string keep = g_err; raisr_hip_destroy(c); g_err = keep; return rc; }
     *out = c;
@@ -1702,7 +1709,7 @@ static hipError_t host_copy(raisr_hip_ctx* c, void* dst, size_t dpitch, const vo
     char* b = c->bounce.take(row_bytes * rows);
     if (!b) return hipErrorOutOfMemory;
     if (h2d) {
-        RowCopyPool::get().copy(b, row_bytes, (const char*)src, spitch, row_bytes, rows);
+        RowCopyPool::get(c->numa_node).copy(b, row_bytes, (const char*)src, spitch, row_bytes, rows);
         hipError_t e = copy_plane(dst, dpitch, b, row_bytes, row_bytes, rows, kind, s);
         if (e != hipSuccess) return e;
         hipEvent_t ev = c->bounce.next_event();                // the bounce memory is reusable once this copy has been executed

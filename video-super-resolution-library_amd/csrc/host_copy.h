@@ -15,11 +15,96 @@
 #include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
+#include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
+
+// ---- NUMA placement (the scaling risk of a multi-GPU host path is pinned memory and copy threads on the wrong socket) ------
+// The bounce memory comes from hipHostMalloc with the context's device current: the runtime places it on the NUMA node closest to that
+// device (no hipHostMallocNumaUser).  What the runtime cannot place are the threads that pack / unpack rows: a process-wide pool would
+// copy every device's rows on whatever cores the scheduler picks.  So there is one pool PER NUMA NODE of the devices in use, its
+// threads bound to that node's CPUs (within the process's own affinity mask); a context uses the pool of its device's node.
+// Single-node hosts, containers without sysfs, RAISR_HIP_NUMA=0: node -1, one unbound pool, as before round 6.
+// RAISR_HIP_SYSFS_ROOT: another root for /sys (tests).
+namespace raisr_numa {
+inline std::string sysfs_root() { const char* e = getenv("RAISR_HIP_SYSFS_ROOT"); return e ? e : "/sys"; }
+
+// "0-15,32-47" -> CPU numbers; empty on any syntax error
+inline std::vector<int> parse_cpulist(const char* text)
+{
+    std::vector<int> out;
+    const char* p = text;
+    while (*p && *p != '\n') {
+        char* end = nullptr;
+        const long lo = strtol(p, &end, 10);
+        if (end == p || lo < 0) return {};
+        long hi = lo;
+        p = end;
+        if (*p == '-') { hi = strtol(p + 1, &end, 10); if (end == p + 1 || hi < lo) return {}; p = end; }
+        for (long c = lo; c <= hi && c < 4096; c++) out.push_back((int)c);
+        if (*p == ',') p++; else if (*p && *p != '\n') return {};
+    }
+    return out;
+}
+
+// NUMA node of the PCI function `bdf` ("0000:c1:00.0"), -1 when unknown or the platform reports none
+inline int node_of_pci(const char* bdf)
+{
+    if (const char* e = getenv("RAISR_HIP_NUMA")) if (e[0] == '0') return -1;
+    std::string b(bdf);
+    for (char& ch : b) if (ch >= 'A' && ch <= 'F') ch = (char)(ch - 'A' + 'a');
+    FILE* f = fopen((sysfs_root() + "/bus/pci/devices/" + b + "/numa_node").c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+inline std::vector<int> cpus_of_node(int node)
+{
+    if (node < 0) return {};
+    FILE* f = fopen((sysfs_root() + "/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return {};
+    char buf[4096];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return parse_cpulist(buf);
+}
+
+// does this host have more than one NUMA node with CPUs?  (one node: nothing to place)
+inline bool multi_node()
+{
+    return !cpus_of_node(0).empty() && !cpus_of_node(1).empty();
+}
+
+// the node a context of the device with PCI address `bdf` should copy on: -1 unless the host has several nodes and the device reports one
+inline int node_for_device(const char* bdf)
+{
+    const int node = node_of_pci(bdf);
+    return (node >= 0 && multi_node() && !cpus_of_node(node).empty()) ? node : -1;
+}
+
+// bind the calling thread to the CPUs of `node` that this process may use; false (and no change) when that set is empty
+inline bool bind_this_thread(int node)
+{
+    const std::vector<int> cpus = cpus_of_node(node);
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    int n = 0;
+    for (int c : cpus) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); n++; }
+    return n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
+}
+}  // namespace raisr_numa
 
 // ---- a few persistent threads for row copies -----------------------------------------------------------------------------------
 // One job at a time; its payload is cut into 128 KB blocks that the workers AND the caller claim from one atomic word
@@ -29,11 +114,18 @@
 // a frame was measured and does not pay: RAISR_HIP_COPY_SPIN.)
 class RowCopyPool {
 public:
-    static RowCopyPool& get()
+    // the pool of NUMA node `node` (-1: the unbound pool); created on first use, never destroyed (its threads may outlive static destructors)
+    static RowCopyPool& get(int node = -1)
     {
-        static RowCopyPool* p = new RowCopyPool();          // never destroyed: its threads may outlive static destructors
+        static std::mutex mu;
+        static std::map<int, RowCopyPool*>* pools = new std::map<int, RowCopyPool*>();
+        std::lock_guard<std::mutex> lk(mu);
+        RowCopyPool*& p = (*pools)[node];
+        if (!p) p = new RowCopyPool(node);
         return *p;
     }
+    int node() const { return node_; }
+    int threads() const { return nthreads_; }
     // dst[r * dpitch .. + row_bytes) = src[r * spitch .. + row_bytes) for r < rows
     void copy(char* dst, size_t dpitch, const char* src, size_t spitch, size_t row_bytes, size_t rows)
     {
@@ -60,7 +152,7 @@ private:
     struct Job { char* dst; const char* src; size_t dpitch, spitch, row_bytes, total; uint64_t gen; };
     static constexpr size_t kBlock = (size_t)128 << 10;
 
-    RowCopyPool()
+    explicit RowCopyPool(int node) : node_(node)
     {
         int n = 3;                                            // + the calling thread
         if (const char* e = getenv("RAISR_HIP_COPY_THREADS")) { n = atoi(e) - 1; if (n < 0) n = 0; if (n > 15) n = 15; }
@@ -127,6 +219,7 @@ private:
     }
     void loop()
     {
+        if (node_ >= 0) (void)raisr_numa::bind_this_thread(node_);     // the rows this pool copies live on node_'s memory
         uint64_t seen = 0;
         for (;;) {
             bool have = false;
@@ -153,10 +246,12 @@ private:
     std::atomic<size_t> left_{0};
     int spin_iters_ = 0;                                     // RAISR_HIP_COPY_SPIN=n: poll n times for the next job before sleeping (measured: no gain, 3 busy cores)
     int nthreads_ = 0;
+    const int node_;
 };
 
 // ---- per-context bounce memory -------------------------------------------------------------------------------------------------
 struct HostBounce {
+    int node = -1;                           // NUMA node of the owning context's device: which RowCopyPool unpacks (raisr_numa)
     char* base = nullptr;
     size_t bytes = 0, used = 0, want = 0;
     struct Unpack { char* dst; size_t dpitch; const char* src; size_t row_bytes, rows; hipEvent_t ev; };
@@ -212,7 +307,7 @@ struct HostBounce {
         for (const Unpack& u : unpack) {
             const hipError_t e = hipEventSynchronize(u.ev);
             if (e != hipSuccess) { if (first == hipSuccess) first = e; continue; }
-            RowCopyPool::get().copy(u.dst, u.dpitch, u.src, u.row_bytes, u.row_bytes, u.rows);
+            RowCopyPool::get(node).copy(u.dst, u.dpitch, u.src, u.row_bytes, u.row_bytes, u.rows);
         }
         unpack.clear();
         return first;

@@ -14,6 +14,23 @@
 #include <vector>
 
 #include "../../include/raisr_hip.h"
+#if defined(RAISR_HIP_DEV) && !defined(RAISR_HIP_TESTHOOKS)
+#define RAISR_HIP_TESTHOOKS 1
+#endif
+#ifdef RAISR_HIP_TESTHOOKS
+#include <atomic>
+#include "../../include/raisr_hip_debug.h"
+// test-hooks flavour only: fault injection into the multi-device model hand-over (RAISR_HIP_TEST_FAIL_BLOB_SLOT=k: the allocation on
+// device slot k "fails") and a count of the per-device staging blobs currently allocated -- tests/test_gpu_stream_multi.py checks that a
+// failure on slot k leaves none of slots 0..k-1 behind
+static std::atomic<int> g_live_blobs{0};
+extern "C" int raisr_hip_debug_stream_live_blobs(void) { return g_live_blobs.load(); }
+static bool injected_failure(size_t slot) { const char* e = getenv("RAISR_HIP_TEST_FAIL_BLOB_SLOT"); return e && *e && (size_t)atoi(e) == slot; }
+#define RAISR_BLOB_LIVE(delta) g_live_blobs.fetch_add(delta)
+#else
+static bool injected_failure(size_t) { return false; }
+#define RAISR_BLOB_LIVE(delta) ((void)0)
+#endif
 
 struct raisr_hip_stream {
     std::vector<int> devices;        // one entry per device slot (a device may appear twice); lane L runs on devices[L % devices.size()]
@@ -158,9 +175,11 @@ int raisr_hip_stream_set_model(raisr_hip_stream* s, int pass_index, const float*
     int rc = raisr_hip_pack_model_blob(host.data(), bank, hashkeys, pixel_types, qstr, qcoh, quant_angle);
     if (rc != RAISR_HIP_OK) return rc;
     std::vector<void*> blobs(nd, nullptr);
-    auto release = [&]() { for (size_t d = 0; d < nd; d++) if (blobs[d]) { (void)hipSetDevice(s->devices[d]); (void)hipFree(blobs[d]); } };
-    for (size_t d = 0; d < nd && rc == RAISR_HIP_OK; d++)
-        if (hipSetDevice(s->devices[d]) != hipSuccess || hipMalloc(&blobs[d], bytes) != hipSuccess) { blobs[d] = nullptr; rc = RAISR_HIP_ENOMEM; }
+    auto release = [&]() { for (size_t d = 0; d < nd; d++) if (blobs[d]) { (void)hipSetDevice(s->devices[d]); (void)hipFree(blobs[d]); blobs[d] = nullptr; RAISR_BLOB_LIVE(-1); } };
+    for (size_t d = 0; d < nd && rc == RAISR_HIP_OK; d++) {
+        if (injected_failure(d) || hipSetDevice(s->devices[d]) != hipSuccess || hipMalloc(&blobs[d], bytes) != hipSuccess) { (void)hipGetLastError(); blobs[d] = nullptr; rc = RAISR_HIP_ENOMEM; }
+        else RAISR_BLOB_LIVE(1);
+    }
     if (rc == RAISR_HIP_OK && (hipSetDevice(s->devices[0]) != hipSuccess || hipMemcpy(blobs[0], host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = RAISR_HIP_ERUNTIME;
     if (rc == RAISR_HIP_OK) rc = raisr_hip_broadcast_model_blob_devices(s->devices.data(), (int)nd, blobs.data(), bytes);
     for (size_t i = 0; i < s->lanes.size() && rc == RAISR_HIP_OK; i++)
