@@ -23,7 +23,11 @@ dt, kern, lanes2, d_in, d_out = b.device_loop(R, torch, wl, 0, bl, lanes_n, fram
 L.raisr_hip_dev_phase_stats(out)
 names = ["window staging + barrier", "gradient tile + barrier", "V pass + barrier + H pass", "approximate hash + certification", "barrier after the hash",
          "worklist (exact path) + barriers", "filter stage", "-"]
+barrier = out[7]
+out[7] = 0                                            # slot 7 = wave-cycles at the workgroup barriers: "of which", not a phase
 tot = sum(out)
 print(f"{cfg}, {lanes_n} lanes, {256 / dt:.0f} fps (instrumented); wave-cycles per phase, share of a wave's life:")
 for n, v in zip(names, out):
     if v: print(f"  {n:38s} {v / tot * 100:5.1f} %   {v * 61 / (256 * wl.passes) / 1e6:8.2f} M wave-cycles per launch (sampled 1 workgroup in 61)")
+if barrier:
+    print(f"  of which parked at the workgroup barriers (arrival -> release, own outstanding memory operations included): {barrier / tot * 100:5.1f} %")

@@ -76,7 +76,19 @@ __device__ __forceinline__ void phase_mark(unsigned long long& t, int k, unsigne
 #define RAISR_PHASE_DECL unsigned long long phase_t = __builtin_amdgcn_s_memtime()
 #define RAISR_PHASE(k) phase_mark(phase_t, (k), tid)
 #define RAISR_PHASE_RESET phase_t = __builtin_amdgcn_s_memtime()
+// the workgroup barriers of k_hashfilter_ac, timed: slot 7 collects the wave-cycles between a wave's arrival at a barrier (its own
+// outstanding memory operations included: __syncthreads drains them) and its release -- "how much of a wave's life is spent parked at the
+// seven barriers of a tile" (round 6; the phases keep counting their barriers too: slot 7 is "of which", not an eighth phase)
+__device__ __forceinline__ void barrier_timed(unsigned tid)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((tid & 63u) == 0 && (blockIdx.y * gridDim.x + blockIdx.x) % 61u == 0u) atomicAdd(&g_phase_cycles[7], t1 - t0);
+}
+#define RAISR_BARRIER(tid) barrier_timed(tid)
 #else
+#define RAISR_BARRIER(tid) __syncthreads()
 #define RAISR_PHASE_DECL
 #define RAISR_PHASE(k)
 #define RAISR_PHASE_RESET

@@ -432,7 +432,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     RAISR_PHASE_DECL;
     if (!DEFER && tid < 4) sCnt[tid] = 0;
     stage_tile<LH, 76, LW>(lr, P.lr_pitch, P.W, P.H, r0 - 6, c0 - 6, sL, tid);
-    __syncthreads();
+    RAISR_BARRIER(tid);
     RAISR_PHASE(0);
     unsigned any_grad = 0u;                                    // OR of the bit patterns of this thread's gradients (x - x is +0: all zero bits <=> flat)
     {   // gradient tile: G(ty,tx) <-> image (r0-5+ty, c0-5+tx) <-> L tile (ty+1, tx+1)
@@ -456,7 +456,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
         }
     }
     if (!DEFER && __any(any_grad != 0u) && lane == 0) sCnt[3] = 1u;  // one LDS store per wave that saw a gradient
-    __syncthreads();
+    RAISR_BARRIER(tid);
     RAISR_PHASE(1);
     // FLAT TILE: not one non-zero gradient in the whole 26 x 74 gradient tile -- letterbox bars, flat graphics, fades to black.  Every
     // window of the tile is flat, so the reference's tensor is exactly (0, 0, 0) for every pixel (as in the per-pixel `zero` case of the
@@ -467,7 +467,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     if (PART == 2) {     // profiling aid: filter stage only; P.cert_check doubles as the bucket pattern (0 = every row of the bank, 1 = one row, 2 = sixteen rows)
         for (int i = tid; i < TH * TW; i += 256) { sH[i] = (uint8_t)(P.cert_check == 1 ? 0 : (P.cert_check == 2 ? (i * 7) % 16 : (i * 7) % 216)); sH2[i] = 0xFFu; }
         if constexpr (PC) copy_window<LW>(sL, sQ, tid);
-        __syncthreads();
+        RAISR_BARRIER(tid);
     } else
 #endif
     if constexpr (DEFER) {
@@ -484,7 +484,7 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
             sH[prow * TW + lane] = zone ? (uint8_t)P.zero_bucket[inA ? 0 : 1] : (uint8_t)0xFFu;
             sH2[prow * TW + lane] = (zone && inA && inB) ? (uint8_t)P.zero_bucket[1] : (uint8_t)0xFFu;
         }
-        if constexpr (PC) { copy_window<LW>(sL, sQ, tid); __syncthreads(); }      // (flat_tile is the same in every thread)
+        if constexpr (PC) { copy_window<LW>(sL, sQ, tid); RAISR_BARRIER(tid); }      // (flat_tile is the same in every thread)
         else __builtin_amdgcn_wave_barrier();
     } else
     hash_phase_ac<LW, GT, RPW, PC>(P, gw, S, sL, sG, sV, sTab, sH, sH2, sList, sCnt, c0, r0, tid, sQ);

@@ -280,7 +280,7 @@ __device__ __forceinline__ void tensor_acN(const SepW& S, const GT* sG, typename
     };
     vpass(lane, w);
     if (w == 0 && lane < 40) vpass(64 + lane % 10, lane / 10);       // the 10 halo columns of all four row groups
-    __syncthreads();
+    RAISR_BARRIER(tid);
 #pragma unroll
     for (int r = 0; r < RPW; r++) { ta[r] = 0.f; tb[r] = 0.f; td[r] = 0.f; }
     // software-pipelined by hand (next column's three vectors in flight during this column's FMAs) and fenced per
@@ -399,7 +399,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         if (nUnc) atomicAdd(&sCnt[1], nUnc);
     }
     RAISR_PHASE(3);                                        // approximate hash + certification
-    __syncthreads();
+    RAISR_BARRIER(tid);
     RAISR_PHASE(4);                                        // ... wait for the other waves
     // pair-column filter stage: its second window copy goes into sV's space now that every wave is past its H pass (behind the table
     // and the tensors of the exact path); the barriers of the worklist -- or the one at the end -- publish it
@@ -413,7 +413,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     unsigned bad = 0;
     if (n) {                                               // the table of VRCP14 / VRSQRT14 takes sV's place (n is the same in every thread;
         if (tid < 128) const_cast<uint2*>(sTab)[tid] = P.tab14[tid];     // every wave is past its last sV read)
-        __syncthreads();
+        RAISR_BARRIER(tid);
     }
     if (n <= kListMax) {
         // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
@@ -435,7 +435,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
                 exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
                 if (l == 0 && e < n) sAbd[e] = float4{a, b, d, 0.0f};
             }
-            __syncthreads();
+            RAISR_BARRIER(tid);
             if (tid < n) {
                 const unsigned ent = sList[tid];
                 const int prow = (ent >> 6) & 15, pcol = ent & 63;
@@ -462,7 +462,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         }
     }
     if (P.cert_stats && bad) atomicAdd(&sCnt[2], bad);
-    if (n || PC) __syncthreads();                          // (n is the same in every thread)
+    if (n || PC) RAISR_BARRIER(tid);                          // (n is the same in every thread)
     RAISR_PHASE(5);                                        // worklist: table staging, exact tensors, exact hashes, three barriers
 }
 
