@@ -1,4 +1,4 @@
-"""GPU box, DEVELOPMENT build (RAISR_HIP_LIB=.../_exp/libraisr_dev.so): wave-cycles per phase of k_hashfilter_ac on one BASELINE configuration
+"""GPU box, DEVELOPMENT build (RAISR_HIP_LIB=.../_exp/libraisr_dev.so): wave-cycles per phase of k_hashfilter_ac (C4: k_hashfilter16) on one BASELINE configuration
 (s_memtime at the phase boundaries of every wave: csrc/kernels_common.h g_phase_cycles).  usage: phase_cycles.py [C2] [lanes]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,8 @@ dt, kern, lanes2, d_in, d_out = b.device_loop(R, torch, wl, 0, bl, lanes_n, fram
 L.raisr_hip_dev_phase_stats(out)
 names = ["window staging + barrier", "gradient tile + barrier", "V pass + barrier + H pass", "approximate hash + certification", "barrier after the hash",
          "worklist (exact path) + barriers", "filter stage", "-"]
+if wl.asm == 5:                                       # binary16 pipeline: k_hashfilter16's marks (csrc/kernels_fp16.h)
+    names = ["window + table staging + barrier", "gradient tile + barrier", "binary16 structure tensor", "per-pixel hash", "two barriers + pair windows", "-", "filter stage", "-"]
 barrier = out[7]
 out[7] = 0                                            # slot 7 = wave-cycles at the workgroup barriers: "of which", not a phase
 tot = sum(out)

@@ -93,6 +93,107 @@ def test_symmetric_lane_program_gives_the_reference_bits(seed):
         assert zero_sign_cases[0] > 0          # the sweep does reach the one case that differs (all products -0, c3 < 0)
 
 
+def lane_major(f):
+    """k_lane_major_bank: float (ch >> 2) * 64 + 4 l + (ch & 3) of the row holds tap 16 ch + l."""
+    out = np.zeros(128, f32)
+    for e in range(128):
+        ch, l = e >> 4, e & 15
+        out[(ch >> 2) * 64 + l * 4 + (ch & 3)] = f[e]
+    return out
+
+
+def redo_lanes(p, f):
+    """The second run of a step that holds a pixel of a non-palindromic row (round 6): the symmetric lane program, but what a lane
+    multiplies after the hand-over comes from a second 16-byte load -- lane l2 = (8 - q) & 15's run of taps 64 + l2 ... 112 + l2 in
+    the lane-major row, 256 B + 16 l2 -- instead of the mirrored registers; lanes >= 9 keep c3 for the padding step."""
+    lm = lane_major(f)
+    a = [None] * 16
+    fa = [[lm[4 * l + c] for c in range(4)] for l in range(16)]
+    for l in range(16):
+        acc = f32(p[l] * fa[l][0])
+        for c in range(1, 4):
+            acc = fma(p[16 * c + l], fa[l][c], acc)
+        a[l] = acc
+    a = [a[(8 - q) % 16] for q in range(16)]                               # partner_xchg
+    for q in range(16):
+        l2 = (8 - q) % 16
+        poff_floats = 64 + 4 * l2                                          # (256 + 16 l2) bytes from the row's start
+        fb = [lm[poff_floats + j] for j in range(4)]
+        if q <= 8:
+            taps = [16 * (4 + j) + l2 for j in range(4)]
+            m = [fb[0], fb[1], fb[2], fb[3]]
+        else:
+            taps = [None] + [16 * (3 + j) + l2 for j in range(1, 4)]
+            m = [fa[q][3], fb[0], fb[1], fb[2]]
+        for j in range(4):
+            x = f32(0) if taps[j] is None else p[taps[j]]
+            a[q] = fma(x, m[j], a[q])
+    return [a[(8 - l) % 16] for l in range(16)], tree(a)
+
+
+def _patch(rng, zeros=0.0):
+    p = np.zeros(128, f32)
+    p[:121] = rng.integers(0, 1024, 121).astype(f32)
+    if zeros:
+        p[:121] *= rng.random(121) >= zeros
+    return p
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_redo_lane_program_gives_the_reference_bits_on_any_row(seed):
+    rng = np.random.default_rng(100 + seed)
+    for trial in range(300):
+        kind = trial % 3
+        if kind == 0:                                                      # one tap pair off, as in filterbin_2_10
+            f = palindrome_row(rng)
+            k = int(rng.integers(0, 60))
+            f[120 - k] = np.nextafter(f[120 - k], f32(10.0)) if trial % 2 else f32(f[120 - k] + f32(1e-6))
+        elif kind == 1:                                                    # nowhere near a palindrome
+            f = np.zeros(128, f32)
+            f[:121] = (rng.standard_normal(121) * 0.1).astype(f32)
+        else:                                                              # a palindrome: the second run reproduces the first
+            f = palindrome_row(rng, negatives=trial % 2 == 0)
+        p = _patch(rng, zeros=0.9 if trial % 5 == 0 else 0.0)
+        (wc, wv), (gc, gv) = reference_lanes(p, f), redo_lanes(p, f)
+        for l in range(16):
+            assert wc[l].view(np.uint32) == gc[l].view(np.uint32) or (l >= 9 and wc[l] == 0 and gc[l] == 0), (trial, l)
+            assert wv[l].view(np.uint32) == gv[l].view(np.uint32) or (wv[l] == 0 and gv[l] == 0), (trial, l)
+        if kind == 2:                                                      # ... bit for bit, signed zeros included
+            (sc, sv) = symmetric_lanes(p, f)
+            assert [x.view(np.uint32) for x in sc] == [x.view(np.uint32) for x in gc]
+
+
+def test_mismatch_in_the_directly_loaded_pairs_costs_nothing():
+    """The stage loads taps 0..63 and mirrors taps 64..120 from 56..0: the pairs (57, 63), (58, 62), (59, 61) are both loaded, so a row
+    that differs from a palindrome only there needs no second run (scan_bank_symmetry compares k <= 56)."""
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        f = palindrome_row(rng)
+        for k in (57, 58, 59)[: 1 + trial % 3]:
+            f[120 - k] = np.nextafter(f[120 - k], f32(-10.0))
+        p = _patch(rng)
+        (wc, wv), (gc, gv) = reference_lanes(p, f), symmetric_lanes(p, f)
+        for l in range(16):
+            assert wc[l].view(np.uint32) == gc[l].view(np.uint32) or (l >= 9 and wc[l] == 0 and gc[l] == 0), (trial, l)
+            assert wv[l].view(np.uint32) == gv[l].view(np.uint32) or (wv[l] == 0 and gv[l] == 0), (trial, l)
+    # and a mismatch at k = 56 does cost: the mirrored tap 64 gets the wrong coefficient
+    f = palindrome_row(rng)
+    f[64] = f32(f[64] + f32(0.25))
+    p = _patch(rng)
+    p[64] = f32(100)
+    assert reference_lanes(p, f)[1][0] != symmetric_lanes(p, f)[1][0]
+
+
+def test_rows_the_symmetric_stage_runs_twice_per_shipped_bank():
+    need = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "filters_*", "*", "filterbin_*"))):
+        a = _bank(path)
+        need[os.path.relpath(path, ROOT)] = int((a[:, :57] != a[:, ::-1][:, :57]).any(axis=1).sum())
+    assert need["filters_2x/filters_highres/filterbin_2_8"] == 2
+    assert need["filters_2x/filters_highres/filterbin_2_10"] == 44       # 50 rows are not palindromes, 6 of them only in taps 57..59 / 61..63
+    assert need["filters_2x/filters_highres/filterbin_2_10_2"] == 1
+
+
 def test_partner_map_is_a_tree_automorphism():
     rng = np.random.default_rng(11)
     for _ in range(50):

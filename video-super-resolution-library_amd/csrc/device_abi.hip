@@ -1026,8 +1026,10 @@ static int build_lane_major_bank(raisr_hip_ctx* c, int pass_index)
     return RAISR_HIP_OK;
 }
 
-// Which rows of the fp32 bank are palindromes (f[k] == f[120 - k], compared as bit patterns)?  Decides whether the symmetric
-// filter stage may run for this model and lists the rows whose pixels it has to redo with all eight coefficient loads.
+// Which rows of the fp32 bank are palindromes where the symmetric filter stage needs them to be (f[k] == f[120 - k] as bit patterns
+// for k <= 56: the stage loads taps 0..63 directly and mirrors taps 64..120 from taps 56..0 -- the pairs (57, 63), (58, 62), (59, 61)
+// are both loaded, a mismatch there costs nothing)?  Decides whether the symmetric filter stage may run for this model and lists the
+// rows whose steps it runs a second time with the true coefficients (kernels_filter.h).
 // `host_bank` = the blob's fp32 bank [rows][128] on the host, or null: then it is read back from the device blob.
 static int scan_bank_symmetry(raisr_hip_ctx* c, int pass_index, const float* host_bank)
 {
@@ -1045,7 +1047,7 @@ static int scan_bank_symmetry(raisr_hip_ctx* c, int pass_index, const float* hos
     for (int r = 0; r < rows && r < 1024; r++) {
         const uint32_t* f = reinterpret_cast<const uint32_t*>(host_bank + (size_t)r * kTapsPad);
         bool pal = true;
-        for (int k = 0; k < 60 && pal; k++) pal = f[k] == f[120 - k];
+        for (int k = 0; k < 57 && pal; k++) pal = f[k] == f[120 - k];
         for (int k = kTaps; k < kTapsPad && pal; k++) pal = f[k] == 0u;            // the padding must be +0 (it is: pack_model_blob)
         if (!pal) { bits[r >> 5] |= 1u << (r & 31); n++; }
     }

@@ -62,8 +62,8 @@ __device__ __forceinline__ float tree16(float acc)
 // eight products are all -0 -- then this lane ends with -0 or +0 where the reference has +0.  A zero chain adds nothing to
 // a tree whose total is not zero, and a zero total fails the accept test either way (clamp_lo >= 0, checked at configure),
 // so the pixel keeps LR in both cases: every stored value has the reference's bits.  (tests/test_sym_filter_model.py
-// replays this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes are listed in
-// P.asym; their pixels are redone with the full eight loads after the row's main loop.
+// replays this lane program on the CPU against the plain 16-lane chains.)  Rows that are not palindromes (in a tap pair the stage
+// mirrors: k <= 56) are listed in P.asym; the steps that hold their pixels run a second time with the true coefficients (below).
 __device__ __forceinline__ float partner_xchg(float v)      // lane p of every row of 16 receives lane (8 - p) & 15
 {
     // (every lane of a row has a source lane: `old` is never used, so it is the source itself and no register is zeroed for it)
@@ -271,6 +271,47 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             }
         }
 #endif
+        // Symmetric stage, pixels of non-palindromic bank rows (round 6; before: the pixel was redone after the accept test with a plain
+        // 16-lane step -- eight recomputed window addresses, its own summation tree, its own accept test).  A step that holds such a pixel
+        // runs AGAIN here, before the row's shared summation tree, with the same lane program on the TRUE coefficients: what a lane
+        // multiplies after the hand-over -- taps 64 + l2, 80 + l2, 96 + l2 (, 112 + l2) of the partner chain l2 = (8 - l) & 15 -- is lane
+        // l2's second run of four in the lane-major bank row (256 B + 16 l2), so ONE more 16-byte load replaces the mirrored registers
+        // (lanes >= 9: behind the padding step, which keeps c3).  The window reads use the loop's own tap addresses with the step's
+        // immediate offset: the steps are unrolled behind wave-uniform branches on the ballot of the row's 64 pixels (PC: a step's pixels
+        // are columns 8 p + j + {0, 2, 4, 6}).  The step's other pixels are recomputed to the same bits (palindromic row: the loaded run
+        // equals the mirrored registers; unfiltered pixel: both loads return +0), so A16[s] is simply replaced and tree, accept test and
+        // store stay shared.  (tests/test_sym_filter_model.py replays this lane program on rows with arbitrary taps.)
+        if (SYM && P.asym) {
+            const bool af = (asym_word >> (asym_key & 31u)) & 1u;          // (0 for a pixel that is not filtered: its word was not loaded)
+            const unsigned long long am = __ballot(af);
+            if (am) {
+                const unsigned poff = 256u + 16u * (unsigned)((8 - l) & 15) - 16u * (unsigned)l;      // from the lane's first run to the partner's second
+                const bool pad_lane = l >= 9;
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    const unsigned long long sm = PC ? (0x55ull << (8 * (s >> 1) + (s & 1))) : (0xFull << (4 * s));
+                    if ((am & sm) == 0) continue;
+                    const unsigned hb = sH[prow * TW + RAISR_COL(s)];
+                    const unsigned voff = __umul24(hb, bank_stride) + row_lane_off;
+                    const u32x4 fa = RAISR_BANK_F4(voff, s), fb = RAISR_BANK_F4(voff + poff, s);
+                    float x[8];
+#pragma unroll
+                    for (int ch = 0; ch < 8; ch++) x[ch] = RAISR_LDS_F(tap[ch], s);
+                    const float m3 = __uint_as_float(pad_lane ? fa[3] : fb[0]), m2 = __uint_as_float(pad_lane ? fb[0] : fb[1]);
+                    const float m1 = __uint_as_float(pad_lane ? fb[1] : fb[2]), m0 = __uint_as_float(pad_lane ? fb[2] : fb[3]);
+                    float acc = x[0] * __uint_as_float(fa[0]);
+                    acc = __builtin_fmaf(x[1], __uint_as_float(fa[1]), acc);
+                    acc = __builtin_fmaf(x[2], __uint_as_float(fa[2]), acc);
+                    acc = __builtin_fmaf(x[3], __uint_as_float(fa[3]), acc);
+                    acc = partner_xchg(acc);
+                    acc = __builtin_fmaf(x[4], m3, acc);
+                    acc = __builtin_fmaf(x[5], m2, acc);
+                    acc = __builtin_fmaf(x[6], m1, acc);
+                    acc = __builtin_fmaf(x[7], m0, acc);
+                    A16[s] = acc + row_ror<0x128>(acc);
+                }
+            }
+        }
 #define RAISR_MERGE(dst, src, mask) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask))
         float B8[8], C4[4], D2[2];
 #pragma unroll
@@ -299,18 +340,6 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         const int csl = RAISR_COL(sl) - RAISR_G0;                                              // the pixel's column in the tile, less the group's base
         float keep = *reinterpret_cast<const float*>(ctr + 4 * csl);
         if (v > P.lo && v < P.hi) keep = v;
-        if (SYM && P.asym) {                                    // pixels whose bank row is not a palindrome: redone with all eight loads
-            const bool af = (asym_word >> (asym_key & 31u)) & 1u;          // (0 for a pixel that is not filtered: its word was not loaded)
-            const unsigned long long am = __ballot(af);
-            if (am) {
-#pragma unroll 1
-                for (int s = 0; s < 16; s++) {
-                    if ((PC ? (am >> (8 * (s >> 1) + (s & 1))) & 0x55ull : (am >> (4 * s)) & 0xFull) == 0) continue;      // the step's pixels (PC: columns 8 p + j + {0, 2, 4, 6})
-                    const float v = plain_step(s, sH[prow * TW + RAISR_COL(s)]);
-                    if (s == sl && ((am >> RAISR_COL(s)) & 1ull)) keep = (v > P.lo && v < P.hi) ? v : RAISR_LDS_F(ctr, s);
-                }
-            }
-        }
         if (__any(anyB)) {                                      // tail columns only: AVX2 re-hash (keep-first-if-rejected;
 #pragma unroll 1                                                 //  Randomness blends the last candidate instead)
             for (int s = 0; s < 16; s++) {

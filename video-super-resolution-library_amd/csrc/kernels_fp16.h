@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256) void k_debug_fold16(Pass16 Q, unsigned long lo
 // of ONE pixel and spent a scalar v_fma_f16 plus a half-extract on B: 3.3 instructions per pixel and tap).
 template <int R, int LW>
 __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& Q, const GaussW16& gw, const hf* sL, uint2* sG,
-                                             const uint16_t* sTab, int c0, int r0, unsigned (&hA)[R])
+                                             const uint16_t* sTab, int c0, int r0, unsigned (&hA)[R], unsigned long long* phase_ptr = nullptr)
 {
+#ifdef RAISR_HIP_DEV
+#define RAISR_PHASE16(k) do { if (phase_ptr) phase_mark(*phase_ptr, (k), threadIdx.x); } while (0)
+#else
+#define RAISR_PHASE16(k)
+#endif
     static_assert(R == 4, "two row pairs per lane");
     constexpr int TH = 4 * R;
     constexpr int GW_ = 74, GH = TH + 9;     // pair rows t = 0 .. TH + 8 (pair t covers gradient rows t and t + 1)
@@ -255,6 +260,7 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
         sG[idx] = make_uint2(__builtin_bit_cast(uint32_t, (hf2){gx0, gx1}), __builtin_bit_cast(uint32_t, (hf2){gy0, gy1}));
     }
     __syncthreads();
+    RAISR_PHASE16(1);                                        // gradient tile + barrier
 
     const hf2 z2 = {(hf)0.f, (hf)0.f};
     // The 11 patch columns in the reference's fold order, as four groups {0,8,4} {2,10,6} {1,9,5} {7,3} = Ga, Gd, Gb, Gc of
@@ -315,6 +321,8 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
                 if (grp == 0 || grp == 2) hold_[q][p] = cur_[q][p];          // Ga, later Gb
             }
     }
+    RAISR_PHASE16(2);                                        // binary16 structure tensor (121 taps x 5 packed operations per pixel pair)
+#undef RAISR_PHASE16
     hf2 *curA = cur_[0], *curB = cur_[1], *curD = cur_[2], *holdA = hold_[0], *holdB = hold_[1], *holdD = hold_[2];
     hf2 *t1A = t1_[0], *t1B = t1_[1], *t1D = t1_[2];
 
@@ -569,6 +577,8 @@ __global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ l
     // loop of 2-byte loads the compiler issued five, waited, and then ran the last three one round trip each: five global round
     // trips in series at the head of every tile -- round 5, R5.10.)
     static_assert(kGBytes % 16 == 0, "the table's LDS copy is 16-byte aligned");
+    const unsigned tid = threadIdx.x;
+    RAISR_PHASE_DECL;                                        // development builds: wave-cycles per phase (scripts/phase_cycles.py C4)
     const uint4 tab_part = reinterpret_cast<const uint4*>(Q.tab16 + 3072)[threadIdx.x];
     {
         TileRegs<LH, 76, T> Rg;
@@ -576,9 +586,14 @@ __global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ l
         reinterpret_cast<uint4*>(sTab)[threadIdx.x] = tab_part;
         store_tile<LH, 76, LW>(Rg, sL);
     }
-    __syncthreads();
+    RAISR_BARRIER(tid);
+    RAISR_PHASE(0);                                          // window + table staging, barrier
     unsigned hA[R];
+#ifdef RAISR_HIP_DEV
+    hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA, &phase_t);
+#else
     hash16_phase<R, LW>(P, Q, gw, sL, sG, sTab, c0, r0, hA);
+#endif
     const int c = c0 + lane;
 #pragma unroll
     for (int j = 0; j < R; j++) {
@@ -586,10 +601,13 @@ __global__ __launch_bounds__(256, 6) void k_hashfilter16(const T* __restrict__ l
         const int r = r0 + w * R + j;
         if (P.write_hash && r < P.H - kMargin && c < P.c_final) hash_out[(size_t)r * P.hash_pitch + c] = (uint8_t)hA[j];
     }
-    __syncthreads();                                         // every wave is done with the gradient tile and the tables
+    RAISR_PHASE(3);                                          // per-pixel hash (marks 1, 2 inside hash16_phase: gradient tile + barrier, tensor)
+    RAISR_BARRIER(tid);                                      // every wave is done with the gradient tile and the tables
     build_pair_windows<LW>(sL + LW + 1, sPA, sPB);
-    __syncthreads();
+    RAISR_BARRIER(tid);
+    RAISR_PHASE(4);                                          // two barriers + pair windows
     filter16_phase<LW, true>(P, Q, sL + LW + 1, sH, c0, r0, hr, sPA, sPB);
+    RAISR_PHASE(6);                                          // filter stage
 }
 
 

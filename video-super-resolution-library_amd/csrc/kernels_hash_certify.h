@@ -392,6 +392,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
         if (unc) {
             const unsigned slot = atomicAdd(sCnt, 1u);
             if (slot < kListMax) sList[slot] = (uint16_t)((prow << 6) | lane | (cert ? 0x8000 : 0));
+#ifdef RAISR_PROBE_L2CERT                                  /* TIMING PROBE (scripts/build_exp.sh l2probe -DRAISR_PROBE_L2CERT), output wrong for ~0.02 % of the pixels: */
+            if (slot < kListMax) reinterpret_cast<float4*>(sG)[slot] = float4{ta[j], tb[j], td[j], 0.0f};    // the listed pixel's APPROXIMATE tensor (the gradient tile is dead: no exact tensor follows)
+#endif
         }
         nUnc += (zone && !cert) ? 1u : 0u;
     }
@@ -427,6 +430,12 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
             // in a one-phase loop every wave issues it for its own 4 entries per round (measured, scripts/r03_call31.sh: C1 +9 %,
             // C2 / C3 / C5 +1.5 %)
             float4* sAbd = reinterpret_cast<float4*>(const_cast<uint2*>(sTab) + 128);
+#ifdef RAISR_PROBE_L2CERT
+            // what a second certification level could save AT MOST: no 16-lane exact tensors and no barrier behind them --
+            // the exact hash runs on the approximate tensors parked at listing time (docs/EXPERIMENTS.md R6)
+            sAbd = reinterpret_cast<float4*>(sG);
+            if (false)
+#endif
             for (unsigned rd = (unsigned)w; 4u * rd < n; rd += 4u) {
                 const unsigned e = 4u * rd + (unsigned)g;
                 const unsigned ent = sList[min(e, n - 1u)];
@@ -435,7 +444,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
                 exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
                 if (l == 0 && e < n) sAbd[e] = float4{a, b, d, 0.0f};
             }
+#ifndef RAISR_PROBE_L2CERT
             RAISR_BARRIER(tid);
+#endif
             if (tid < n) {
                 const unsigned ent = sList[tid];
                 const int prow = (ent >> 6) & 15, pcol = ent & 63;
