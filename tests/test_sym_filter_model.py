@@ -105,7 +105,9 @@ def lane_major(f):
 def redo_lanes(p, f):
     """The second run of a step that holds a pixel of a non-palindromic row (round 6): the symmetric lane program, but what a lane
     multiplies after the hand-over comes from a second 16-byte load -- lane l2 = (8 - q) & 15's run of taps 64 + l2 ... 112 + l2 in
-    the lane-major row, 256 B + 16 l2 -- instead of the mirrored registers; lanes >= 9 keep c3 for the padding step."""
+    the lane-major row, 256 B + 16 l2 -- instead of the mirrored registers; lanes >= 9 load from 4 bytes earlier, so that the padding
+    step (window value +0) meets the float in front of the run (tap 111 + l2: tap 120 or a padding zero) and taps 64 + l2, 80 + l2,
+    96 + l2 the same registers as in lanes <= 8.  The same program with both loads in EVERY step is the 32-byte form of a tile row (MIX)."""
     lm = lane_major(f)
     a = [None] * 16
     fa = [[lm[4 * l + c] for c in range(4)] for l in range(16)]
@@ -122,9 +124,10 @@ def redo_lanes(p, f):
         if q <= 8:
             taps = [16 * (4 + j) + l2 for j in range(4)]
             m = [fb[0], fb[1], fb[2], fb[3]]
-        else:
+        else:                                                              # the lane loads from 4 bytes earlier: the float in front meets the zero block
             taps = [None] + [16 * (3 + j) + l2 for j in range(1, 4)]
-            m = [fa[q][3], fb[0], fb[1], fb[2]]
+            m = [lm[poff_floats - 1], fb[0], fb[1], fb[2]]
+            assert np.isfinite(m[0])
         for j in range(4):
             x = f32(0) if taps[j] is None else p[taps[j]]
             a[q] = fma(x, m[j], a[q])
@@ -158,9 +161,11 @@ def test_redo_lane_program_gives_the_reference_bits_on_any_row(seed):
         for l in range(16):
             assert wc[l].view(np.uint32) == gc[l].view(np.uint32) or (l >= 9 and wc[l] == 0 and gc[l] == 0), (trial, l)
             assert wv[l].view(np.uint32) == gv[l].view(np.uint32) or (wv[l] == 0 and gv[l] == 0), (trial, l)
-        if kind == 2:                                                      # ... bit for bit, signed zeros included
-            (sc, sv) = symmetric_lanes(p, f)
-            assert [x.view(np.uint32) for x in sc] == [x.view(np.uint32) for x in gc]
+        if kind == 2:                                                      # ... bit for bit, up to the sign of a zero chain of a padded lane
+            (sc, sv) = symmetric_lanes(p, f)                               # (its padding step multiplies +0 by another finite coefficient)
+            for l in range(16):
+                assert sc[l].view(np.uint32) == gc[l].view(np.uint32) or (l >= 9 and sc[l] == 0 and gc[l] == 0), (trial, l)
+                assert sv[l].view(np.uint32) == gv[l].view(np.uint32) or (sv[l] == 0 and gv[l] == 0), (trial, l)
 
 
 def test_mismatch_in_the_directly_loaded_pairs_costs_nothing():

@@ -252,12 +252,36 @@ __device__ __forceinline__ void hash16_phase(const PassParams& P, const Pass16& 
     constexpr int TH = 4 * R;
     constexpr int GW_ = 74, GH = TH + 9;     // pair rows t = 0 .. TH + 8 (pair t covers gradient rows t and t + 1)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (unsigned idx = threadIdx.x; idx < (unsigned)(GH * GW_); idx += 256) {
-        const int ty = (int)(idx / GW_), tx = (int)(idx - (unsigned)ty * GW_);
-        const hf* c = sL + ty * LW + tx + 1;                 // column of the vertical differences
-        const hf gx0 = c[2 * LW] - c[0], gx1 = c[3 * LW] - c[LW];
-        const hf gy0 = c[LW + 1] - c[LW - 1], gy1 = c[2 * LW + 1] - c[2 * LW - 1];
-        sG[idx] = make_uint2(__builtin_bit_cast(uint32_t, (hf2){gx0, gx1}), __builtin_bit_cast(uint32_t, (hf2){gy0, gy1}));
+    // Gradient tile.  Pair row t holds the gradients of window rows t and t + 1: gx[t] = L[t+2][x+1] - L[t][x+1], gy[t] = L[t+1][x+2] - L[t+1][x],
+    // and the second half of pair t is the first half of pair t + 1.  Lane = column, a wave walks down its 6-7 pair rows with the three
+    // window rows of gx in registers: 3 LDS reads and 2 subtractions per row (round 6; before: every entry on its own -- 8 reads, 4
+    // subtractions and an index division per entry, 58 reads per thread: 14.6 % of a wave's life, profiles/r06_call7_phase_cycles_C4.txt).
+    // Same subtractions on the same operands.  The ten halo columns 64..73: one entry per thread, the old way.
+    {
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        __builtin_assume(wu >= 0 && wu < 4);
+        static_assert(GH == 25, "pair rows 0..24 over four waves: 7 + 6 + 6 + 6");
+        const int t0 = wu == 0 ? 0 : 6 * wu + 1, cnt = wu == 0 ? 7 : 6;
+        const hf* col = sL + t0 * LW + lane + 1;             // L[t0][x + 1]
+        hf la = col[0], lb = col[LW];                        // L[t], L[t + 1]
+        hf gxp = (hf)0.f, gyp = (hf)0.f;
+#pragma unroll
+        for (int i = 0; i <= 7; i++) {                       // single rows t0 + i, i = 0..cnt (cnt is wave-uniform)
+            if (i <= cnt) {
+                const hf lc = col[(i + 2) * LW];
+                const hf gx = lc - la;
+                const hf gy = col[(i + 1) * LW + 1] - col[(i + 1) * LW - 1];
+                if (i > 0) sG[(t0 + i - 1) * GW_ + lane] = make_uint2(__builtin_bit_cast(uint32_t, (hf2){gxp, gx}), __builtin_bit_cast(uint32_t, (hf2){gyp, gy}));
+                gxp = gx; gyp = gy; la = lb; lb = lc;
+            }
+        }
+        if (threadIdx.x < (unsigned)(GH * (GW_ - 64))) {
+            const int ty = (int)(threadIdx.x / (GW_ - 64)), tx = 64 + (int)(threadIdx.x - (unsigned)ty * (GW_ - 64));
+            const hf* c = sL + ty * LW + tx + 1;             // column of the vertical differences
+            const hf gx0 = c[2 * LW] - c[0], gx1 = c[3 * LW] - c[LW];
+            const hf gy0 = c[LW + 1] - c[LW - 1], gy1 = c[2 * LW + 1] - c[2 * LW - 1];
+            sG[ty * GW_ + tx] = make_uint2(__builtin_bit_cast(uint32_t, (hf2){gx0, gx1}), __builtin_bit_cast(uint32_t, (hf2){gy0, gy1}));
+        }
     }
     __syncthreads();
     RAISR_PHASE16(1);                                        // gradient tile + barrier

@@ -416,7 +416,10 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
     unsigned bad = 0;
     if (n) {                                               // the table of VRCP14 / VRSQRT14 takes sV's place (n is the same in every thread;
         if (tid < 128) const_cast<uint2*>(sTab)[tid] = P.tab14[tid];     // every wave is past its last sV read)
-        RAISR_BARRIER(tid);
+        // Short list: the table is first read by the one-lane hashes, BEHIND the barrier that follows the 16-lane tensors (which touch
+        // neither the table nor its place) -- that barrier publishes it (round 6: one workgroup barrier fewer per listed tile, and the
+        // table's global round trip overlaps the tensors).  Long list: hash_phase reads the table right away.
+        if (n > kListMax) RAISR_BARRIER(tid);
     }
     if (n <= kListMax) {
         // short list (the usual case): 16 lanes per pixel, four pixels per wave and round
@@ -431,8 +434,9 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
             // C2 / C3 / C5 +1.5 %)
             float4* sAbd = reinterpret_cast<float4*>(const_cast<uint2*>(sTab) + 128);
 #ifdef RAISR_PROBE_L2CERT
-            // what a second certification level could save AT MOST: no 16-lane exact tensors and no barrier behind them --
-            // the exact hash runs on the approximate tensors parked at listing time (docs/EXPERIMENTS.md R6)
+            // what a second certification level could save AT MOST: no 16-lane exact tensors (one barrier per listed tile was
+            // removed for every build in round 6: the table's own) -- the exact hash runs on the approximate tensors parked at listing time
+            // (docs/EXPERIMENTS.md R6)
             sAbd = reinterpret_cast<float4*>(sG);
             if (false)
 #endif
@@ -444,9 +448,7 @@ __device__ __forceinline__ void hash_phase_ac(const PassParams& P, const GaussW&
                 exact_tensor16(sG, wl, prow, pcol, l, a, b, d);
                 if (l == 0 && e < n) sAbd[e] = float4{a, b, d, 0.0f};
             }
-#ifndef RAISR_PROBE_L2CERT
-            RAISR_BARRIER(tid);
-#endif
+            RAISR_BARRIER(tid);                               // publishes the tensors AND the table
             if (tid < n) {
                 const unsigned ent = sList[tid];
                 const int prow = (ent >> 6) & 15, pcol = ent & 63;
