@@ -1,8 +1,8 @@
 """-m gpu: the symmetric filter stage on banks with non-palindromic rows (csrc/kernels_filter.h, filter_phase<.., SYM>).
 
 The stage runs the steps that hold pixels of non-palindromic bank rows a second time with the true coefficients (round 6; before: a plain
-16-lane redo after the accept test), or -- per-row choice, banks with 17..64 such rows -- loads both runs of four in every step of a tile row
-with more than RAISR_HIP_MIX_MAX such pixels; the shipped highres banks exercise that with 2 (8-bit) / 44 (10-bit) of 864 rows only.  Here the highres bank gets 1 .. 400 of its rows perturbed (one tap
+16-lane redo after the accept test); the shipped highres banks exercise that with 2 (8-bit) of 864 rows only (the 10-bit bank's 44 rows are
+above the threshold: eight-load stage).  Here the highres bank gets 1 .. 400 of its rows perturbed (one tap
 moved by an ulp, or a row replaced by noise), so that steps with 0, 1 and 4 such pixels, tail re-hash columns (width 134) and
 Randomness blending all meet the redo path -- compared bit for bit with the CPU oracle on the same bank, and with the eight-load
 stage (RAISR_HIP_SYM=0).  Above 16 such rows (RAISR_HIP_SYM_MAX_ROWS) the library keeps the eight-load stage by itself: same
@@ -91,12 +91,7 @@ def test_non_palindromic_rows_bit_exact(nasym, bits):
                 assert np.array_equal(plain, got), (nasym, bits, w, h, name, blending, "eight-load stage differs")
                 forced = _gpu(y, bank, qstr, qcoh, qa, bits, R.HASH_AVX512, blending, preset, env={"RAISR_HIP_SYM_MAX_ROWS": "1000"})
                 assert np.array_equal(forced, got), (nasym, bits, w, h, name, blending, "symmetric stage with second runs differs")
-                # the per-row choice (round 6) whatever the number of rows: rows of the tile with more than 0 / 1 / 3 such pixels take the
-                # 32-byte form of the lane program, the others the 16-byte loop + second runs
-                for mm in ("0", "1", "3"):
-                    mixed = _gpu(y, bank, qstr, qcoh, qa, bits, R.HASH_AVX512, blending, preset,
-                                 env={"RAISR_HIP_SYM_MAX_ROWS": "0", "RAISR_HIP_MIX_MAX_ROWS": "1000", "RAISR_HIP_MIX_MAX": mm})
-                    assert np.array_equal(mixed, got), (nasym, bits, w, h, name, blending, "per-row choice differs, mix_max = " + mm)
+
 
 
 def test_redo_path_on_a_larger_frame_with_every_step_pattern():

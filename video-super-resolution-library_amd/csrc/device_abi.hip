@@ -249,8 +249,6 @@ struct raisr_hip_ctx {
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
     int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
-    int mix_max_rows = 64;                     // ... above that and up to this many: the same stage with a per-row choice of 16 or 32 coefficient bytes per lane (RAISR_HIP_MIX_MAX_ROWS; 0 = off)
-    int mix_max = 1;                           // ... whose rows with more than this many pixels of non-palindromic bank rows take the 32-byte form (RAISR_HIP_MIX_MAX)
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool defer = false;                        // RAISR_HIP_DEFER=1: uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist
                                                // (bit-exact; measured slower on every configuration, docs/EXPERIMENTS.md: k_fix_ac costs more than the main kernel gains)
@@ -398,7 +396,6 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.zero_bucket[0] = m.zero_bucket[0]; P.zero_bucket[1] = m.zero_bucket[1];
     P.gauss_dev = c->d_gauss;
     P.asym = (m.asym_rows > 0) ? m.d_asym : nullptr;
-    P.mix_max = c->mix_max;
     return P;
 }
 
@@ -448,7 +445,7 @@ bool launch_dev_variant(raisr_hip_ctx* c, hipStream_t s, int pass, const void* l
 // at P.tile_y0), followed -- deferred exact path -- by k_fix_ac on the same tiles.  The self-check mode (cert_check: every pixel also
 // takes the exact path) and RAISR_HIP_DEFER=0 use the in-tile worklist variant.
 template <typename TOut>
-void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void* lrp, const PassParams& P, dim3 grid, int sym, dim3 plane_tiles)     // sym: 0 eight-load stage, 1 symmetric, 2 symmetric with the per-row choice
+void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void* lrp, const PassParams& P, dim3 grid, bool sym, dim3 plane_tiles)
 {
     int slot;
 #ifdef RAISR_HIP_TESTHOOKS
@@ -468,8 +465,7 @@ void launch_hashfilter_ac(raisr_hip_ctx* c, hipStream_t s, int pass, const void*
     }
 #endif
     timer_begin(c, "k_hashfilter_ac", s, slot);
-    if (sym == 2) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true, false, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
-    else if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
+    if (sym) hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0, 4, true>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
     else hipLaunchKernelGGL((k_hashfilter_ac<TOut, 0>), grid, dim3(256), 0, s, (const TOut*)lrp, P, c->gauss, c->sep, c->d_hash[pass], c->d_hr[pass], FixAc{});
     timer_end(c, s, slot);
 }
@@ -499,12 +495,11 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
         dim3 gf((P.c_final - kMargin + 63) / 64, (H - 2 * kMargin + 15) / 16);
         const bool avx2all = !(P.a_end > P.a_begin);        // asm=avx2: no 16-wide chunks at all
         const int asym_rows = c->model[pass].asym_rows;
-        int sym = (c->sym && asym_rows >= 0 && asym_rows <= c->sym_max_rows) ? 1 : 0;   // symmetric filter stage of k_hashfilter_ac
-        if (c->sym && !sym && asym_rows >= 0 && asym_rows <= c->mix_max_rows) sym = 2;   // ... with the per-row choice (a few dozen non-palindromic rows)
+        bool sym = c->sym && asym_rows >= 0 && asym_rows <= c->sym_max_rows;   // symmetric filter stage of k_hashfilter_ac
 #ifdef RAISR_HIP_DEV
         // TIMING PROBE, output wrong for pixels on non-palindromic rows: the symmetric stage whatever the bank, nothing redone -- what
         // a free treatment of those rows would be worth (docs/EXPERIMENTS.md)
-        if (getenv("RAISR_HIP_SYM_IGNORE_ASYM")) { sym = 1; P.asym = nullptr; }
+        if (getenv("RAISR_HIP_SYM_IGNORE_ASYM")) { sym = true; P.asym = nullptr; }
 #endif
 #ifdef RAISR_HIP_TESTHOOKS
         if (c->fast || (c->fused && c->certify && c->split)) {
@@ -813,8 +808,6 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
-    if (const char* e = getenv("RAISR_HIP_MIX_MAX_ROWS")) c->mix_max_rows = atoi(e);
-    if (const char* e = getenv("RAISR_HIP_MIX_MAX")) { const int v = atoi(e); c->mix_max = v < 0 ? 0 : (v > 64 ? 64 : v); }
 #ifdef RAISR_HIP_DEV
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
 #else

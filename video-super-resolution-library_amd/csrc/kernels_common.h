@@ -42,7 +42,6 @@ struct PassParams {
                                  // tap 16 ch + l -- the four (eight) coefficients of zmm lane l are one (two) 16-byte loads (k_lane_major_bank)
     const uint32_t* asym;        // symmetric filter stage (filter_phase<.., SYM>): bitmap [32 words] of the (bucket * pixel_types + type) bank rows
                                  // that are NOT palindromic (f[k] != f[120-k] for a k <= 56), or null when every row is
-    int mix_max;                 // filter_phase<.., SYM, PC, MIX>: a tile row with more pixels of such bank rows than this loads both runs of four in every step
     // frame batches (raisr_hip_process_y_device_batch): blockIdx.z = frame; plane f of a batch starts f * zs_* ELEMENTS after plane 0
     // (all 0 for a single frame).  Only the production kernels (k_hashfilter_ac, k_blend, k_hashfilter16, k_blend16) read these.
     size_t zs_lr, zs_hr, zs_hash, zs_out;

@@ -85,17 +85,12 @@ __device__ __forceinline__ float partner_xchg(float v)      // lane p of every r
 // 26 x 76 floats; the caller builds it in LDS that is dead by then).  The type column (c - 5) & 1 = (j + 1) & 1 (c0 is even) no longer
 // depends on the lane: it travels in the coefficient loads' scalar offset.  Same operations on the same operands: the pixel -> lane
 // group assignment is free.
-// MIX (with SYM, round 6): banks with a few dozen non-palindromic rows (filterbin_2_10: 44 of 864; 3-6 % of a picture's pixels, scattered: two
-// to four per tile row).  The stage decides PER TILE ROW: a row with at most P.mix_max such pixels runs the 16-byte loop and the second run
-// of the affected steps; a row with more runs the SAME lane program with both 16-byte loads in every step (the partner's run of four
-// for the taps behind the hand-over) -- the bytes of the eight-load stage, no second runs.  The row's bitmap word is requested one row ahead.
-template <int LW, int RPW = 4, bool SYM = false, bool PC = false, bool MIX = false>
+template <int LW, int RPW = 4, bool SYM = false, bool PC = false>
 __device__ __forceinline__ void filter_phase(const PassParams& P, const float* sL, const uint8_t* sH, const uint8_t* sH2,
                                              int c0, int r0, float* __restrict__ hr, unsigned tid = threadIdx.x, const float* zpad = nullptr,
                                              const float* sQ = nullptr)
 {
     constexpr int TW = 64;
-    static_assert(!MIX || SYM, "the per-row choice is a variant of the symmetric stage");
     static_assert(!PC || (LW % 2) == 0, "pair columns: 8-byte window reads need an even row stride");
     const int lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l = lane & 15;
@@ -125,21 +120,12 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #define RAISR_COL(s) (PC ? 8 * ((s) >> 1) + 2 * g + ((s) & 1) : 4 * (s) + g)
 #define RAISR_G0 (PC ? 2 * g : g)
     const unsigned bank_stride = (unsigned)(P.pixel_types * kTapsPad * 4);   // bytes per hash bucket (<= 2048)
-    // Symmetric stage, true coefficients of the taps behind the hand-over (second runs, MIX rows): lane l2 = (8 - l) & 15's run of taps
+    // Symmetric stage, true coefficients of the taps behind the hand-over (second runs of the steps that hold pixels of non-palindromic rows): lane l2 = (8 - l) & 15's run of taps
     // 64 + l2 .. 112 + l2 in the lane-major row, 256 + 16 l2 bytes into it.  Lanes >= 9 multiply the padding step first and then taps
     // 64 + l2, 80 + l2, 96 + l2: they load from 4 bytes EARLIER, so that the same registers serve both lane classes -- the float in front
     // (tap 111 + l2: tap 120 or padding zeros) meets the +0 of the zero block (any finite coefficient will do there, see above; a 16-byte
     // buffer load needs 4-byte alignment only, and none of these straddles a 128-byte line).
     const unsigned poff = 256u + 16u * (unsigned)((8 - l) & 15) - 16u * (unsigned)l - (l >= 9 ? 4u : 0u);
-    // the symmetric stage's look-up "is this lane's pixel (row prow, column c0 + lane) in a non-palindromic bank row?"
-    auto asym_request = [&](int prow_, int r_, unsigned& word, unsigned& key) {
-        const unsigned hrow = sH[prow_ * TW + lane];
-        key = __umul24(hrow, (unsigned)P.pixel_types) + ((P.pixel_types == 4) ? (unsigned)(((r_ - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
-        word = 0u;
-        if (hrow != 0xFFu) word = P.asym[key >> 5];
-    };
-    unsigned asym_word_n = 0u, asym_key_n = 0u;                   // MIX: requested one row ahead (the row's loop variant depends on it)
-    if (MIX && P.asym) asym_request(RPW * w, r0 + RPW * w, asym_word_n, asym_key_n);
 
 #pragma unroll 1                                                 // (unrolled 2x / 4x: no difference, r04_call16)
     for (int row = 0; row < RPW; row++) {
@@ -191,15 +177,10 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // used after the row's steps -- asked for there, its global round trip ended every row with an exposed s_waitcnt vmcnt(0)
         // (round 5, R5.10: C2 +1.3 %)
         unsigned asym_word = 0u, asym_key = 0u;
-        unsigned long long am = 0ull;                               // the row's pixels in non-palindromic bank rows (bit = column in the tile)
-        bool full_row = false;                                      // MIX: this row loads both runs of four in every step
         if (SYM && P.asym) {
-            if constexpr (MIX) {
-                asym_word = asym_word_n; asym_key = asym_key_n;
-                if (row + 1 < RPW) asym_request(prow + 1, r + 1, asym_word_n, asym_key_n);
-                am = __ballot((asym_word >> (asym_key & 31u)) & 1u);
-                full_row = __builtin_popcountll(am) > P.mix_max;
-            } else asym_request(prow, r, asym_word, asym_key);
+            const unsigned hrow = sH[prow * TW + lane];
+            asym_key = __umul24(hrow, (unsigned)P.pixel_types) + ((P.pixel_types == 4) ? (unsigned)(((r - 5) & 1) * 2 + ((lane + 1) & 1)) : 0u);
+            if (hrow != 0xFFu) asym_word = P.asym[asym_key >> 5];
         }
         // The row's 16 steps (4 adjacent pixels each) share ONE summation tree.  sumitup_ps_512 halves the number of distinct
         // values per step at every level (16 lanes -> r8[0..7] -> r4[0..3] -> r2[0..1] -> v), so after each level two steps are
@@ -228,7 +209,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             }
             return acc + row_ror<0x128>(acc);                   // r8[i] = a[i] + a[i+8]: lanes i and i ^ 8 hold the same value
         };
-        // symmetric lane program on both runs of four (second runs, MIX rows): q[4..7] = the partner's run (lanes >= 9: from 4 bytes earlier)
+        // symmetric lane program on both runs of four (second runs): q[4..7] = the partner's run (lanes >= 9: from 4 bytes earlier)
         auto chain_full = [&](const float (&x)[8], const float (&q)[8]) -> float {
             float acc = x[0] * q[0];
             acc = __builtin_fmaf(x[1], q[1], acc);
@@ -259,8 +240,7 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
 #ifdef RAISR_PROBE_FILTER_STEPS                                  /* development builds: timing probe from kernels_probes.h (output wrong) */
         RAISR_PROBE_FILTER_STEPS
 #else
-        auto run_steps = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;        // (MIX rows only) both runs of four per step
+        {
             // The steps, software-pipelined by hand in pairs (a ds_read2_b32 fetches one tap of two steps): the coefficient loads and
             // window reads of pair p + 1 are issued before the arithmetic of pair p, the bucket bytes one pair earlier still, with a
             // scheduling fence per pair.  Against the compiler's own schedule (loads six steps ahead, window reads just in time):
@@ -298,29 +278,21 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
             };
 #pragma unroll
             for (int s = 0; s < 2 * AHEAD + 2; s++) issue_h(s);
-            auto ldq = [&](unsigned hb, float (&q)[8], int s) { if constexpr (FULL) load_q_full(hb, q, s); else load_q(hb, q, s); };
 #pragma unroll
-            for (int s = 0; s < 2 * AHEAD; s++) ldq(bucket_of(s), Q[s], s);
+            for (int s = 0; s < 2 * AHEAD; s++) load_q(bucket_of(s), Q[s], s);
             issue_xx(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                if (p + AHEAD < 8) { ldq(bucket_of(2 * (p + AHEAD)), Q[2 * (p + AHEAD)], 0); ldq(bucket_of(2 * (p + AHEAD) + 1), Q[2 * (p + AHEAD) + 1], 1); }
+                if (p + AHEAD < 8) { load_q(bucket_of(2 * (p + AHEAD)), Q[2 * (p + AHEAD)], 0); load_q(bucket_of(2 * (p + AHEAD) + 1), Q[2 * (p + AHEAD) + 1], 1); }
                 if (p + AHEAD + 1 < 8) { issue_h(2 * (p + AHEAD + 1)); issue_h(2 * (p + AHEAD + 1) + 1); }
                 if (p + 1 < 8) issue_xx(p + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (FULL) {
-                    A16[2 * p] = chain_full(X[2 * p], Q[2 * p]);
-                    A16[2 * p + 1] = chain_full(X[2 * p + 1], Q[2 * p + 1]);
-                } else {
-                    A16[2 * p] = chain(X[2 * p], Q[2 * p]);
-                    A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1]);
-                }
+                A16[2 * p] = chain(X[2 * p], Q[2 * p]);
+                A16[2 * p + 1] = chain(X[2 * p + 1], Q[2 * p + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        if constexpr (MIX) { if (full_row) run_steps(std::true_type{}); else run_steps(std::false_type{}); }
-        else run_steps(std::false_type{});
+        }
 #endif
         // Symmetric stage, pixels of non-palindromic bank rows (round 6; before: the pixel was redone after the accept test with a plain
         // 16-lane step -- eight recomputed window addresses, its own summation tree, its own accept test).  A step that holds such a pixel
@@ -333,8 +305,8 @@ __device__ __forceinline__ void filter_phase(const PassParams& P, const float* s
         // equals the mirrored registers; unfiltered pixel: both loads return +0), so A16[s] is simply replaced and tree, accept test and
         // store stay shared.  (tests/test_sym_filter_model.py replays this lane program on rows with arbitrary taps.)
         if (SYM && P.asym) {
-            if constexpr (!MIX) am = __ballot((asym_word >> (asym_key & 31u)) & 1u);      // (0 for a pixel that is not filtered: its word was not loaded)
-            if (am && !full_row) {
+            const unsigned long long am = __ballot((asym_word >> (asym_key & 31u)) & 1u);      // (0 for a pixel that is not filtered: its word was not loaded)
+            if (am) {
 #pragma unroll
                 for (int s = 0; s < 16; s++) {
                     const unsigned long long sm = PC ? (0x55ull << (8 * (s >> 1) + (s & 1))) : (0xFull << (4 * s));
@@ -482,7 +454,7 @@ __device__ __forceinline__ void copy_window(const float* sL, float* sQ, unsigned
     for (unsigned i = tid; i < 26u * LW; i += 256u) sQ[i] = sL[LW + 1 + i];      // sQ[e] = sP[e], sP = sL + LW + 1: window position (r0 - 5, c0 - 5)
 }
 
-template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false, bool DEFER = false, bool PC = false, bool MIX = false>
+template <typename T, int PART, int LW, int LH, int GW_, int GH, typename GT, int RPW = 4, bool SYM = false, bool DEFER = false, bool PC = false>
 __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, const PassParams& P, const GaussW& gw, const SepW& S,
                                                    uint8_t* __restrict__ hash_out, float* __restrict__ hr, int bx, int by,
                                                    float* sL, GT* sG, typename FVec<RPW>::type* sV, uint2* sTab, uint8_t* sH, uint8_t* sH2, uint16_t* sList, unsigned* sCnt, unsigned tid = threadIdx.x,
@@ -579,12 +551,12 @@ __device__ __forceinline__ void hashfilter_ac_tile(const T* __restrict__ lr, con
     // wave's own rows of sV (row group w of channel 0: read by wave w's H pass only, which is over).
     float* zpad = DEFER ? reinterpret_cast<float*>(sV + w * GW_) : reinterpret_cast<float*>(sG) + 64 * w;
     if (SYM && PART != 1) zpad[lane] = 0.0f;
-    if (PART != 1) filter_phase<LW, RPW, SYM, PC, MIX>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, zpad, sQ);
+    if (PART != 1) filter_phase<LW, RPW, SYM, PC>(P, sL + LW + 1, sH, sH2, c0, r0, hr, tid, zpad, sQ);
     else if (sH[tid & (TH * TW - 1)] == 0xFEu) hr[0] = 0.f;       // keep the hash stage alive
     RAISR_PHASE(6);
 }
 
-template <typename T, int PART = 0, int RPW = 4, bool SYM = false, bool DEFER = false, bool MIX = false>
+template <typename T, int PART = 0, int RPW = 4, bool SYM = false, bool DEFER = false>
 #ifdef RAISR_EXP_OCC5
 #define RAISR_AC_WGS 5
 #else
@@ -626,7 +598,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? RAISR_AC_WGS : 6) void k_hashfilter
     by += P.tile_y0;
     lr += blockIdx.z * P.zs_lr; hr += blockIdx.z * P.zs_hr; hash_out += blockIdx.z * P.zs_hash;    // frame batches
     const unsigned tile_id = blockIdx.z * F.zs_tiles + (unsigned)by * (unsigned)F.tiles_x + (unsigned)bx;
-    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM, DEFER, PC, MIX>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, threadIdx.x, F, tile_id, sQ);
+    hashfilter_ac_tile<T, PART, LW, LH, GW_, GH, GT, RPW, SYM, DEFER, PC>(lr, P, gw, S, hash_out, hr, bx, by, sL, sG, sV, sTab, sH, sH2, sList, sCnt, threadIdx.x, F, tile_id, sQ);
 }
 
 
