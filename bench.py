@@ -57,7 +57,7 @@ L1_PROBE_B_PER_CLK_CU = 55.0                                 # scripts/l1_width_
 N_CUS = 256
 CLOCK_HZ = 2.4e9
 VALU_FP16_PEAK_TFLOPS = 314.6                                # packed binary16 (v_pk_fma_f16): two lanes per fp32 lane, same issue rate
-# (scripts/valu_rate_probe.hip sustains 911 G wave-inst/s = 116.6 TFLOP/s of v_fma_f32 on this power-limited part.)
+# (scripts/valu_rate_probe.hip sustains ~911 G wave-inst/s = ~116.6 TFLOP/s of v_fma_f32 on this power-limited part: profiles/valu_rate_probe.json)
 # SURVEY.md s8d per-filtered-pixel ALGORITHMIC FLOP model (FMA = 2): structure tensor 121 x (2 mul + 3 fma) + 45 add,
 # hash ~60, filter 121 fma + 15 add.  This is the work the reference's algorithm defines per pixel; a kernel that
 # reaches the same bits with fewer instructions (certified approximate tensor) shows up as a higher achieved rate.
@@ -252,6 +252,39 @@ def measured_traffic(kernel, config="C2"):
     return None, "no PMC pass recorded for these kernel sources (run scripts/profile_gpu.sh)"
 
 
+def measured_binding(kernel, config="C2"):
+    """What keeps `kernel` busy in configuration `config`, from the counters of the newest profiles/traffic_r*.json recorded for these
+    kernel sources (scripts/summarize_profiles.py writes a `binding` object next to the traffic: vector-instruction rate against the
+    measured v_fma_f32 rate, LDS-busy share, waiting share); (None, why) otherwise -- figures of another kernel or configuration are not
+    quoted (round 5 printed C2's typed-in percentages on C1's line)."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        cands = sorted(f for f in os.listdir(pdir) if f.startswith("traffic_r") and f.endswith(".json"))
+    except OSError:
+        return None, "no profiles/ directory"
+    cur = source_hash()
+    for fn in reversed(cands):
+        try:
+            j = json.load(open(os.path.join(pdir, fn)))
+        except (OSError, ValueError):
+            continue
+        if j.get("source_sha256") != cur or j.get("config", "C2") != config or j.get("variant_env"):
+            continue
+        b = j.get("binding")
+        if b and b.get("kernel") == kernel:
+            return b, fn
+    return None, "no counter pass recorded for these kernel sources and this configuration (run scripts/profile_gpu.sh)"
+
+
+def valu_probe_rate():
+    """Sustained v_fma_f32 rate of this part (scripts/valu_rate_probe.hip) as recorded in profiles/valu_rate_probe.json: (TFLOP/s, source)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "valu_rate_probe.json")))
+        return float(j["v_fma_f32_TFLOP_per_s"]), "profiles/valu_rate_probe.json (" + j.get("from", "") + ")"
+    except (OSError, ValueError, KeyError):
+        return None, "no probe record (scripts/valu_rate_probe.hip)"
+
+
 def bind_to_gpu_numa_node(torch, gpu):
     """N > 1: run this rank on the CPUs of the NUMA node its GPU hangs off, so that the page-locked frame planes of the streamed leg
     (first touch) and the threads that fill them are local to the PCIe root (NUMA placement of pinned buffers).
@@ -424,7 +457,9 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
                             "unit": ("TFLOP/s (packed binary16 VALU" if fp16 else "TFLOP/s (fp32 VALU") + ", algorithmic FLOPs of SURVEY s8d)",
                             "frac": round(tflops / peak, 4)}
         if not fp16:                                 # what scripts/valu_rate_probe.hip sustains on this (power-limited) part with pure v_fma_f32
-            roofline["valu"].update({"sustained_peak": 116.6, "frac_of_sustained": round(tflops / 116.6, 4)})
+            sp, sp_src = valu_probe_rate()
+            if sp:
+                roofline["valu"].update({"sustained_peak": sp, "sustained_peak_source": sp_src, "frac_of_sustained": round(tflops / sp, 4)})
         roofline["binding"] = "f16-valu" if fp16 else "fp32-valu"
         # Coefficient delivery through the vector L1 (profiles/r03_l1_width_probe.md: ~55 B/clk/CU whatever the load width).  Round 3 took
         # this floor for the binding one; round 4 halved the bytes (symmetric filter stage) and the kernel moved 2 %: it is reported as a
@@ -435,11 +470,20 @@ def roofline_of(wl, kern, iso, lanes_n, batch=1):
                           "floor_ms": round(floor_ms, 4), "isolated_ms": round(iso[dom], 4) if dom in iso else None,
                           "frac": round(floor_ms / iso[dom], 4) if dom in iso else None,
                           "what": "vector-L1 delivery floor of the filter stage's coefficients / isolated launch of the dominant kernel (a floor, not the bound)"}
-        if not fp16:
-            roofline["binding"] = ("instruction issue at 16 waves per CU with no pipe saturated: vector ALU ~61 % (at the 2.7 cycles per v_fma_f32 the part "
-                                   "sustains), LDS ~43 % (60 % before the filter stage's 8-byte window reads, R5.11), vector L1 ~40 % (~63 % for models whose bank is not symmetric) of the kernel's cycles; a fifth workgroup "
-                                   "per CU, prefetching and barrier removal change nothing, removing instructions does (rocprofv3 SQ counters and timing "
-                                   "probes, docs/EXPERIMENTS.md I.1, I.4); fp32-valu utilisation is the figure to watch")
+        # what the dominant kernel keeps busy: counters of THIS configuration on THESE kernel sources, or nothing (no typed-in figures)
+        b, bsrc = measured_binding(dom, wl.name)
+        l1f = roofline["l1"]["frac"]
+        if b:
+            pct = lambda x: "n/a" if x is None else f"{100 * x:.0f} %"
+            roofline["binding"] = {
+                "what": ("binary16 " if fp16 else "fp32 ") + "vector-instruction issue at the occupancy LDS and registers allow, no pipe saturated (DESIGN.md s5)",
+                "valu_of_probe_rate": b.get("valu_of_probe_rate"), "lds_busy": b.get("lds_busy"), "vector_l1_floor_frac": l1f,
+                "wave_cycles_waiting_for_an_instruction": b.get("wave_cycles_waiting_for_an_instruction"),
+                "summary": f"vector ALU {pct(b.get('valu_of_probe_rate'))} of the measured v_fma_f32 rate, LDS {pct(b.get('lds_busy'))} busy, "
+                           f"vector-L1 coefficient floor {pct(l1f)} of the isolated launch, {pct(b.get('wave_cycles_waiting_for_an_instruction'))} of the wave cycles waiting for an instruction",
+                "source": f"profiles/{bsrc}: {b.get('from', '')}"}
+        else:
+            roofline["binding"] = {"what": ("f16-valu" if fp16 else "fp32-valu") + " instruction issue (DESIGN.md s5)", "vector_l1_floor_frac": l1f, "summary": None, "source": bsrc}
     return roofline
 
 

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 echo "$*" > "$OUT/variant.txt"
 BARGS=""
-for kv in "$@"; do case "$kv" in --*|C[1-5]|[0-9]*) BARGS="$BARGS $kv";; *) export "$kv";; esac; done      # "--config C3" goes to bench.py, KEY=VAL to the environment
+for kv in "$@"; do case "$kv" in --*|C[1-5]|C[1-5][a-z]|[0-9]*) BARGS="$BARGS $kv";; *) export "$kv";; esac; done      # "--config C3" goes to bench.py, KEY=VAL to the environment
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-extras$BARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --steps 3 --warmup 1 > "$OUT/stats.log" 2>&1

@@ -22,10 +22,10 @@ def short(name):
 
 
 variant = open(os.path.join(src, "variant.txt")).read().strip() if os.path.exists(os.path.join(src, "variant.txt")) else ""
-m = re.search(r"--config\s+(C\d)", variant)
+m = re.search(r"--config\s+(C\d\w?)", variant)
 config = m.group(1) if m else "C2"
 variant_env = " ".join(t for t in variant.split() if "=" in t and not t.startswith("--"))
-DESC = {"C1": "540p->1080p 2x, lowres, 1-pass, AVX2 numerics", "C2": "1080p->4K 2x, highres, 1-pass", "C3": "1080p->4K 2x, highres, 2-pass",
+DESC = {"C1": "540p->1080p 2x, lowres, 1-pass, AVX2 numerics", "C2": "1080p->4K 2x, highres, 1-pass", "C2b": "1080p->4K 2x, highres, 1-pass, 10-bit (the reference's published configuration)", "C3": "1080p->4K 2x, highres, 2-pass",
         "C4": "720p->1080p 1.5x, denoise, 2-pass mode 2, binary16 numerics", "C5": "4K->8K 2x, highres, 10-bit"}
 lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-extras --config {config} --steps 3 --warmup 1` ({config}: {DESC[config]}, 4 lanes x 768 frames/step)"
          + (f", environment: `{variant_env}`" if variant_env else ""), ""]
@@ -107,7 +107,27 @@ if pmc:
         for fn in sorted(os.listdir(cs)):                      # same digest as bench.py source_hash(): the figure is only quoted for these sources
             if fn.endswith((".hip", ".h")) and fn != "host_copy.h":
                 hs.update(fn.encode()); hs.update(open(os.path.join(cs, fn), "rb").read())
-        json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic,
+        # what the dominant kernel keeps busy (bench.py's roofline.binding reads this instead of typed-in figures): vector-instruction
+        # rate against the measured v_fma_f32 rate of the part, LDS-busy share of the CU-cycles of the isolated launch, share of the wave
+        # cycles spent waiting for an instruction (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)
+        binding = None
+        v = pmc.get(dom, {})
+        t_ms = iso.get(alias.get(dom, dom)) if dom else None
+        if t_ms and "SQ_INSTS_VALU" in v:
+            CLOCK_HZ, N_CUS, PROBE_G = 2.4e9, 256, 911.0            # bench.py's constants; scripts/valu_rate_probe.hip (profiles/valu_rate_probe.json when recorded)
+            try:
+                PROBE_G = float(json.load(open(os.path.join(dst, "valu_rate_probe.json")))["v_fma_f32_G_wave_inst_per_s"])
+            except Exception:
+                pass
+            rate = v["SQ_INSTS_VALU"] / fpl / (t_ms * 1e-3) / 1e9
+            binding = {"kernel": dom, "isolated_us_per_frame": round(t_ms * 1e3, 1),
+                       "valu_G_wave_inst_per_s": round(rate, 1), "valu_of_probe_rate": round(rate / PROBE_G, 3),
+                       "lds_busy": round(v["SQ_LDS_IDX_ACTIVE"] / fpl / (t_ms * 1e-3 * CLOCK_HZ * N_CUS), 3) if "SQ_LDS_IDX_ACTIVE" in v else None,
+                       "lds_cycles_lost_to_bank_conflicts": round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 3) if v.get("SQ_LDS_IDX_ACTIVE") else None,
+                       "wave_cycles_waiting_for_an_instruction": round(v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in v else None,
+                       "l2_hit_rate": round(v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 1.0)), 3) if "TCC_HIT_sum" in v else None,
+                       "from": f"profiles/{tag}_rocprof_summary.md (rocprofv3 --pmc passes, --lanes 1)"}
+        json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic, "binding": binding,
                    "source_sha256": hs.hexdigest(), "config": config, "variant_env": variant_env,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--lanes 1); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                              "gfx950 FETCH_SIZE half-count confirmed on k_blend's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
