@@ -248,6 +248,7 @@ struct raisr_hip_ctx {
     bool fused = true;                         // one k_hashfilter launch per pass instead of k_hash + k_filter (RAISR_HIP_FUSED=0)
     bool fold16 = true;                        // binary16 hash: strength / coherence thresholds folded onto the dividends (RAISR_HIP_FOLD16=0 keeps the divisions)
     bool sym = true;                           // symmetric filter stage for banks whose rows are (nearly all) palindromes; RAISR_HIP_SYM=0 keeps the eight-load stage
+    int blend_rows = 8;                        // census blend: rows per wave of k_blend4 / k_blend4_16 (4, 8, 16), 0 = always the 64 x 16 LDS-tile kernels (RAISR_HIP_BLEND_ROWS: A/B switch)
     int sym_max_rows = 16;                     // ... chosen when at most this many rows are not (RAISR_HIP_SYM_MAX_ROWS); their pixels are redone with eight loads
     bool certify = true;                       // certified hash stage (k_hashfilter_ac / k_hash_ac); RAISR_HIP_CERTIFY=0 keeps the all-exact kernels
     bool defer = false;                        // RAISR_HIP_DEFER=1: uncertified pixels go to a per-frame list and k_fix_ac instead of the in-tile worklist
@@ -397,6 +398,35 @@ PassParams make_pass(raisr_hip_ctx* c, int pass, int W, int H)
     P.gauss_dev = c->d_gauss;
     P.asym = (m.asym_rows > 0) ? m.d_asym : nullptr;
     return P;
+}
+
+// census blend of a range of 16-row tile rows (first: P.tile_y0): the four-columns-per-lane kernel when the planes' rows are 4-sample
+// aligned (every video size), the 64 x 16 LDS-tile kernel otherwise
+template <typename TOut>
+void launch_blend(raisr_hip_ctx* c, hipStream_t s, const void* lrp, const float* hr, const PassParams& P, void* out, int out_pitch_elems, unsigned tile_rows, unsigned nz)
+{
+    int slot;
+    timer_begin(c, "k_blend", s, slot);
+    const int rw = blend4_fits<TOut>(lrp, hr, out, out_pitch_elems, P, sizeof(float)) ? c->blend_rows : 0;
+    const unsigned W = (unsigned)P.W;
+    if (rw == 4) hipLaunchKernelGGL((k_blend4<TOut, 4>), dim3((W + 255) / 256, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, (TOut*)out, out_pitch_elems);
+    else if (rw == 8) hipLaunchKernelGGL((k_blend4<TOut, 8>), dim3((W + 511) / 512, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, (TOut*)out, out_pitch_elems);
+    else if (rw == 16) hipLaunchKernelGGL((k_blend4<TOut, 16>), dim3((W + 1023) / 1024, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, (TOut*)out, out_pitch_elems);
+    else hipLaunchKernelGGL((k_blend<TOut>), dim3((W + 63) / 64, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
+}
+template <typename TOut>
+void launch_blend16(raisr_hip_ctx* c, hipStream_t s, const void* lrp, const uint16_t* hr, const PassParams& P, const Pass16& Q, void* out, int out_pitch_elems, unsigned tile_rows, unsigned nz)
+{
+    int slot;
+    timer_begin(c, "k_blend16", s, slot);
+    const int rw = blend4_fits<TOut>(lrp, hr, out, out_pitch_elems, P, sizeof(uint16_t)) ? c->blend_rows : 0;
+    const unsigned W = (unsigned)P.W;
+    if (rw == 4) hipLaunchKernelGGL((k_blend4_16<TOut, 4>), dim3((W + 255) / 256, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, Q.c_avx, (TOut*)out, out_pitch_elems);
+    else if (rw == 8) hipLaunchKernelGGL((k_blend4_16<TOut, 8>), dim3((W + 511) / 512, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, Q.c_avx, (TOut*)out, out_pitch_elems);
+    else if (rw == 16) hipLaunchKernelGGL((k_blend4_16<TOut, 16>), dim3((W + 1023) / 1024, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, Q.c_avx, (TOut*)out, out_pitch_elems);
+    else hipLaunchKernelGGL((k_blend16<TOut>), dim3((W + 63) / 64, tile_rows, nz), dim3(256), 0, s, (const TOut*)lrp, hr, P, Q, (TOut*)out, out_pitch_elems);
+    timer_end(c, s, slot);
 }
 
 // one RAISR pass on an LR plane already resident in c->d_lr[pass]
@@ -573,9 +603,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
                 const int b1 = i == nchunks - 1 ? Tb : t1;
                 P.tile_y0 = t0;
                 launch_hashfilter_ac<TOut>(c, s, pass, lrp, P, dim3(gf.x, (unsigned)(t1 - t0)), sym, gf);
-                timer_begin(c, "k_blend", s, slot);
-                hipLaunchKernelGGL((k_blend<TOut>), dim3((W + 63) / 64, (unsigned)(b1 - t0)), dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
-                timer_end(c, s, slot);
+                launch_blend<TOut>(c, s, lrp, (const float*)c->d_hr[pass], P, out, out_pitch_elems, (unsigned)(b1 - t0), 1u);
                 const int r0 = 16 * t0, r1 = i == nchunks - 1 ? H : 16 * t1;
                 done(r0, r1 - r0);
             }
@@ -623,10 +651,7 @@ void run_pass(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pitc
     static const bool skip_blend = getenv("RAISR_HIP_SKIP_BLEND") != nullptr;
     if (skip_blend) { done(0, H); return; }
 #endif
-    dim3 gb((W + 63) / 64, (H + 15) / 16, nz);
-    timer_begin(c, "k_blend", s, slot);
-    hipLaunchKernelGGL((k_blend<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const float*)c->d_hr[pass], P, (TOut*)out, out_pitch_elems);
-    timer_end(c, s, slot);
+    launch_blend<TOut>(c, s, lrp, (const float*)c->d_hr[pass], P, out, out_pitch_elems, (unsigned)((H + 15) / 16), nz);
     done(0, H);
 }
 
@@ -686,10 +711,7 @@ void run_pass16(raisr_hip_ctx* c, hipStream_t s, int pass, void* out, int out_pi
         timer_end(c, s, slot);
         return;
     }
-    dim3 gb((W + 63) / 64, (H + 15) / 16, nz);
-    timer_begin(c, "k_blend16", s, slot);
-    hipLaunchKernelGGL((k_blend16<TOut>), gb, dim3(256), 0, s, (const TOut*)lrp, (const uint16_t*)c->d_hr[pass], P, Q, (TOut*)out, out_pitch_elems);
-    timer_end(c, s, slot);
+    launch_blend16<TOut>(c, s, lrp, (const uint16_t*)c->d_hr[pass], P, Q, out, out_pitch_elems, (unsigned)((H + 15) / 16), nz);
 }
 
 void free_scratch(raisr_hip_ctx* c)
@@ -808,6 +830,7 @@ static int create_impl(raisr_hip_ctx* c)
     if (const char* e = getenv("RAISR_HIP_FOLD16")) c->fold16 = atoi(e) != 0;
     if (const char* e = getenv("RAISR_HIP_SYM")) c->sym = atoi(e) != 0;           // A/B switch: 0 = eight coefficient loads per pixel whatever the bank
     if (const char* e = getenv("RAISR_HIP_SYM_MAX_ROWS")) c->sym_max_rows = atoi(e);
+    if (const char* e = getenv("RAISR_HIP_BLEND_ROWS")) { const int v = atoi(e); c->blend_rows = (v == 4 || v == 8 || v == 16) ? v : 0; }   // A/B switch: 0 = the LDS-tile blend kernels
 #ifdef RAISR_HIP_DEV
     if (const char* e = getenv("RAISR_HIP_FAST")) { const int v = atoi(e); c->fast = v < 0 ? 0 : (v > 2 ? 2 : v); }         // NON-bit-exact fast mode (see raisr_hip_set_fast)
 #else
