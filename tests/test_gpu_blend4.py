@@ -70,3 +70,34 @@ def test_blend_extreme_samples():
         ref = oracle_y(y, case)
         for rows in (0, 4, 8, 16):
             assert np.array_equal(ref, _gpu(y, case, rows)), rows
+
+
+@pytest.mark.parametrize("bits", [8, 10, 16])
+def test_resize_3_2_blocks_bit_exact(bits):
+    """k_resize3x2 (a thread: 12 x 3 outputs) against the oracle's cheap upscale: sizes off the 12-column / 3-row block seams, both tie
+    rules, 4-byte aligned and unaligned destination rows (12-sample stores / single-sample stores), extreme samples."""
+    import oracle_py as O
+    import raisr_hip as R
+    import torch
+    dt = dtype_for(bits)
+    tdt = torch.uint8 if bits == 8 else torch.uint16
+    bps = 1 if bits == 8 else 2
+    rng = np.random.default_rng(bits)
+    for tie in (R.TIE_HALF_UP, R.TIE_HALF_EVEN):
+        dev = R.RaisrDevice(0)
+        dev.set_model_from_folder(folder("filters_1.5x/filters_highres"), 8, 1)
+        dev.configure(16, 16, 24, 24, bits=8, passes=1, mode=1, tie=tie)        # the plane entry takes the context's tie rule
+        for sw, sh in ((16, 8), (22, 10), (86, 50), (128, 30), (130, 34), (1280, 6)):
+            dw, dh = sw * 3 // 2, sh * 3 // 2
+            planes = [rng.integers(0, 1 << bits, (sh, sw)).astype(dt), np.full((sh, sw), (1 << bits) - 1, dt), (np.indices((sh, sw)).sum(0) % 2 * ((1 << bits) - 1)).astype(dt)]
+            for y in planes:
+                ref = O.resize(y, dw, dh, tie).astype(dt)
+                for pad in (0, 1, 4):                                            # destination pitch = dw + pad samples
+                    d_in = torch.from_numpy(y).cuda()
+                    d_out = torch.zeros((dh, dw + pad), dtype=tdt, device="cuda")
+                    dev.resize_plane(d_in.data_ptr(), sw, sh, sw * bps, d_out.data_ptr(), dw, dh, (dw + pad) * bps, bits)
+                    dev.synchronize()
+                    got = d_out.cpu().numpy()
+                    assert np.array_equal(got[:, :dw], ref), (bits, tie, sw, sh, pad, int((got[:, :dw] != ref).sum()))
+                    assert not got[:, dw:].any()
+        dev.close()

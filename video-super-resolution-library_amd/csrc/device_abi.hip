@@ -355,7 +355,7 @@ void launch_resize(raisr_hip_ctx* c, hipStream_t s, const void* src, void* dst, 
         dim3 grid(((R.dw + 7) / 8 + 63) / 64, (R.sh + 3) / 4, nz);       // a thread: 8 x 2 output pixels
         hipLaunchKernelGGL((k_resize2x<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (2 * R.dw == 3 * R.sw && 2 * R.dh == 3 * R.sh) {
-        dim3 grid(((R.dw + 2) / 3 + 63) / 64, (R.dh + 3) / 4, nz);
+        dim3 grid(((R.dw + 11) / 12 + 63) / 64, ((R.dh + 2) / 3 + 3) / 4, nz);   // a thread: 12 x 3 output pixels
         hipLaunchKernelGGL((k_resize3x2<TIn, TOut>), grid, dim3(256), 0, s, (const TIn*)src, (TOut*)dst, R);
     } else if (R.dw == R.sw && R.dh == R.sh) {
         dim3 grid((R.dw + 63) / 64, (R.dh + 3) / 4, nz);

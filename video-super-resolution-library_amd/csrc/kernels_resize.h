@@ -185,39 +185,92 @@ __global__ __launch_bounds__(256) void k_resize2x(const TIn* __restrict__ src, T
 }
 
 // 3:2 special case (the reference's 1.5x models): n = 4 d - 1 over den = 6 per axis, so output d = 3 m + e reads sources
-// 2 m - 1 + e and 2 m + e with weights {1,5}, {3,3}, {5,1} (/6) for e = 0, 1, 2; out = floor((2 num + 36) / 72) [half-up].
-// One thread produces 3 adjacent output pixels of one row from 2 x 4 source samples; same arithmetic as k_resize.
+// 2 m - 1 + e and 2 m + e with weights {1,5}, {3,3}, {5,1} (/6) for e = 0, 1, 2; out = floor((2 num + 36) / 72) [half-up]
+// = floor((num + 18) / 36), num <= 36 * 65535.  Same arithmetic as k_resize.
+// One thread produces a 12 x 3 block of output pixels -- output rows 3 n .. 3 n + 2 and columns 12 j .. 12 j + 11 -- from source rows
+// 2 n - 1 .. 2 n + 2 and source columns 8 j - 1 .. 8 j + 8 (replicate-clamped): 40 single-sample loads, 4 vertical sums per source
+// column, one or two operations, an addition and ONE multiply-high per output (floor(x / 36) = mulhi(x, ceil(2^32 / 36)) for
+// x < 2^27), three 12-sample stores.  Round 6: the 3 x 1 version spent 38 vector and 3.7 memory instructions per output pixel
+// (5.5 % of C4's GPU time); the kernel runs beside the other frames' issue-bound k_hashfilter16, so its instructions are what it
+// costs (docs/EXPERIMENTS.md R5.9, R6.10).
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, TOut* __restrict__ dst, ResizeParams R)
 {
     src += blockIdx.z * R.zs_src; dst += blockIdx.z * R.zs_dst;
     int bx, by;
-    xcd_tile(bx, by);
-    const int m = bx * 64 + (threadIdx.x & 63);               // group of 3 output columns
-    const int y = by * 4 + (threadIdx.x >> 6);
-    const int x0 = 3 * m;
-    if (x0 >= R.dw || y >= R.dh) return;
-    const int ny = y / 3, ey = y - 3 * ny;                    // (division by a constant: multiply-high)
-    const int ya = min(max(2 * ny - 1 + ey, 0), R.sh - 1), yb = min(2 * ny + ey, R.sh - 1);
-    const unsigned fy = 5u - 2u * (unsigned)ey, gy = 6u - fy; // weights of yb and ya
-    const TIn* ra = src + (size_t)ya * R.spitch;
-    const TIn* rb = src + (size_t)yb * R.spitch;
-    unsigned v[4];
+    xcd_tile(bx, by);                                         // vertically adjacent blocks share input rows: keep them on one XCD
+    const int j = bx * 64 + (threadIdx.x & 63);               // group of 12 output columns
+    const int n = by * 4 + (threadIdx.x >> 6);                // group of 3 output rows
+    const int x0 = 12 * j, y0 = 3 * n;
+    if (x0 >= R.dw || y0 >= R.dh) return;
+    unsigned col[10], row[4];                                 // source columns 8 j - 1 .. 8 j + 8, rows 2 n - 1 .. 2 n + 2, replicate-clamped
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = min(max(2 * m - 1 + i, 0), R.sw - 1);
-        v[i] = gy * ((unsigned)ra[c] >> R.in_shift) + fy * ((unsigned)rb[c] >> R.in_shift);
+    for (int k = 0; k < 10; k++) col[k] = (unsigned)min(max(8 * j - 1 + k, 0), R.sw - 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) row[k] = (unsigned)min(max(2 * n - 1 + k, 0), R.sh - 1) * (unsigned)R.spitch;
+    unsigned s[4][10];                                        // single-sample loads at 32-bit offsets (planes are < 2^31 samples), as k_resize2x
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 10; k++) s[r][k] = (unsigned)src[row[r] + col[k]];
+    if (R.in_shift) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 10; k++) s[r][k] >>= R.in_shift;
     }
-    TOut* d = dst + (size_t)y * R.dpitch + x0;
+    const bool vec = (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (((unsigned)R.dpitch * sizeof(TOut)) & 3) == 0 && x0 + 11 < R.dw;   // x0 * sizeof(TOut) is a multiple of 4
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
-        if (x0 + e >= R.dw) break;
-        const unsigned fx = 5u - 2u * (unsigned)e;
-        const unsigned num = (6u - fx) * v[e] + fx * v[e + 1];           // <= 36 * 65535
-        const unsigned t = 2u * num + 36u;
-        unsigned q = t / 72u;
-        if (R.tie_even && t - 72u * q == 0u && (q & 1u)) q--;
-        d[e] = (TOut)(q << R.out_shift);
+    for (int ey = 0; ey < 3; ey++) {
+        const int y = y0 + ey;
+        if (y >= R.dh) break;
+        // output row 3 n + ey: source rows (2 n - 1 + ey, 2 n + ey) = s[ey], s[ey + 1] with weights (gy, fy) = (1,5), (3,3), (5,1)
+        unsigned v[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            v[k] = ey == 0 ? 5u * s[1][k] + s[0][k] : (ey == 1 ? 3u * (s[1][k] + s[2][k]) : 5u * s[2][k] + s[3][k]);
+        unsigned o[12];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                         // outputs 3 g + e of the block: group m = 4 j + g reads v[2 g + e], v[2 g + e + 1]
+            o[3 * g + 0] = 5u * v[2 * g + 1] + v[2 * g];             // weights (1, 5)
+            o[3 * g + 1] = 3u * (v[2 * g + 1] + v[2 * g + 2]);       //         (3, 3)
+            o[3 * g + 2] = 5u * v[2 * g + 2] + v[2 * g + 3];         //         (5, 1)
+        }
+        // (2 num + 36) / 72 = (num + 18) / 36;  floor(t / 36) = mulhi(t, 119304648): 119304648 = ceil(2^32 / 36), exact for t < 2^27
+        if (R.tie_even) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const unsigned t = o[i] + 18u;
+                unsigned q = __umulhi(t, 119304648u);
+                if (t - 36u * q == 0u && (q & 1u)) q--;
+                o[i] = q;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; i++) o[i] = __umulhi(o[i] + 18u, 119304648u);
+        }
+        if (R.out_shift) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) o[i] <<= R.out_shift;
+        }
+        TOut* p = dst + (size_t)y * R.dpitch + x0;
+        if (vec) {
+            if (sizeof(TOut) == 1) {
+                unsigned w[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) w[k] = (o[4 * k] & 0xffu) | ((o[4 * k + 1] & 0xffu) << 8) | ((o[4 * k + 2] & 0xffu) << 16) | (o[4 * k + 3] << 24);
+                *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);          // (two stores: the block is 4-byte, not 16-byte aligned)
+                reinterpret_cast<unsigned*>(p)[2] = w[2];
+            } else {
+                unsigned w[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) w[k] = (o[2 * k] & 0xffffu) | (o[2 * k + 1] << 16);
+#pragma unroll
+                for (int k = 0; k < 3; k++) reinterpret_cast<uint2*>(p)[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+            }
+        } else {
+            for (int i = 0; i < 12 && x0 + i < R.dw; i++) p[i] = (TOut)o[i];
+        }
     }
 }
 
