@@ -64,7 +64,7 @@ if pmc:
     lines += ["", "Units: SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves; FETCH_SIZE / WRITE_SIZE are KiB as reported.",
               "Calibration on known byte counts of these kernels' own access patterns (MI355X_MICROARCH.md asks for one):",
               "* WRITE_SIZE: k_resize2x writes exactly one u8 LR plane, 8 294 400 B = 8 100 KiB == WRITE_SIZE -> no correction.",
-              "* FETCH_SIZE: k_blend has to fetch the LR plane (u8, 8.29 MB) and the HR plane (f32, 33.18 MB) that the previous",
+              "* FETCH_SIZE: k_blend4 (k_blend before round 6) has to fetch the LR plane (u8, 8.29 MB) and the HR plane (f32, 33.18 MB) that the previous",
               "  kernels wrote -- 41.5 MB per launch at the very least (the 4 MiB L2s cannot hold them; Infinity-Cache hits are",
               "  counted) -- and FETCH_SIZE reports half of that: the gfx950 half-count (128-B requests tallied at 64 B) applies to",
               "  these row-coalesced loads too, so FETCH_SIZE is doubled below, as the guide prescribes.", ""]
@@ -77,7 +77,7 @@ if pmc:
         fpl = int(jj.get("config", {}).get("frames_per_launch", 1)) or 1
     except Exception:
         pass
-    alias = {"k_resize2x": "k_resize"}
+    alias = {"k_resize2x": "k_resize", "k_resize3x2": "k_resize", "k_blend4": "k_blend", "k_blend4_16": "k_blend16"}
     rows = []
     for k, v in pmc.items():
         t_ms = iso.get(alias.get(k, k))
@@ -130,7 +130,7 @@ if pmc:
         json.dump({"dominant_kernel": dom, "dominant_kernel_hbm_bytes_per_launch": traffic.get(dom), "per_kernel_bytes": traffic, "binding": binding,
                    "source_sha256": hs.hexdigest(), "config": config, "variant_env": variant_env,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--lanes 1); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
-                             "gfx950 FETCH_SIZE half-count confirmed on k_blend's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
+                             "gfx950 FETCH_SIZE half-count confirmed on k_blend4's known byte count, WRITE_SIZE exact on k_resize2x's, see the summary"},
                   open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
