@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
 // A row of a plane is one aligned load per lane (4 samples: 4 / 8 bytes of LR, 16 / 8 bytes of HR) plus one one-sample load for
 // the two columns outside the wave (lane 63: column c0 + 256, every other lane: column c0 - 1); the left / right neighbours of a
 // lane's outer columns come from the adjacent lanes through DPP wave shifts (wave_shr:1 / wave_shl:1, whose `old` operand is
-// exactly that outside column for lane 0 / lane 63).  The 3-row window slides down in registers; all rows of a wave's first
-// group are requested before the first is consumed, the next group's while the current one is computed.  Arithmetic per pixel:
+// exactly that outside column for lane 0 / lane 63).  The 3-row window slides down in registers, rows are requested one ahead of
+// their use.  Arithmetic per pixel:
 // the very expressions of k_blend / k_blend16 (same operations, same order).
 // ------------------------------------------------------------------------------------------------
 template <typename TOut> struct Lr4;
@@ -272,19 +272,18 @@ __device__ __forceinline__ void blend4_wave(const TOut* __restrict__ lr, const t
     };
 
     Raw q[RW + 2];
-    constexpr int G0 = RW < 8 ? RW + 2 : 6;                  // rows requested before the first is consumed
+    // Three rows are requested before the first is consumed, one more per output row: enough to cover the latency beside the other
+    // frames' main kernel, and 56-65 registers -- a wave of this kernel fits into what four waves of k_hashfilter_ac leave of a
+    // SIMD's 512 (96 beside the symmetric stage's 4 x 104, 64 beside the eight-load stage's 4 x 112).  Requesting six rows first and
+    // four at a time (94-113 registers) was no faster anywhere and 0.7 % slower on the 16-bit planes of C5 (R6.9).
 #pragma unroll
-    for (int i = 0; i < G0; i++) request(i, q[i]);
+    for (int i = 0; i < 3; i++) request(i, q[i]);
     float l[3][6], h[3][6];
     unpack(0, q[0], l[1], h[1]);
     unpack(1, q[1], l[2], h[2]);
 #pragma unroll
     for (int rr = 0; rr < RW; rr++) {
-        if (rr % 4 == 0) {                                   // the next four rows are requested while these four are computed
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (rr + 6 + i < RW + 2 && rr + 6 + i >= G0) request(rr + 6 + i, q[rr + 6 + i]);
-        }
+        if (rr + 3 < RW + 2) request(rr + 3, q[rr + 3]);
         const int y = r0 + rr;                               // rows below the plane are computed on repeated rows and not stored
 #pragma unroll
         for (int j = 0; j < 6; j++) { l[0][j] = l[1][j]; l[1][j] = l[2][j]; h[0][j] = h[1][j]; h[1][j] = h[2][j]; }
