@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256, RPW == 4 ? RAISR_AC_WGS : 6) void k_hashfilter
     // Second window copy of the pair-column filter stage: in sV's space behind the exact path's table (1 KB) and tensors (kListMax x 16 B),
     // 26 x LW floats.  Its dword offset from the window, mod 64, decides the bank conflicts of the stage's 8-byte reads (two groups of 32
     // lanes, 64 banks): with LW = 78 the offsets 0, 2, 40, 42 are conflict-free for every tap chunk of both stage variants
-    // (tests/test_filter_window_banks.py replays the bank arithmetic); 3680 B into sV gives 40.
-    constexpr unsigned oQ = oV + 3680;
+    // (tests/test_filter_window_banks.py replays the bank arithmetic); 5216 B into sV gives 40 (3680 with the 160-entry list of rounds 3-5).
+    constexpr unsigned oQ = oV + 5216;
     static_assert(!PC || (oQ >= oV + 1024 + kListMax * 16 && oQ + 26 * LW * 4 <= oH && oQ % 8 == 0), "second window copy: inside sV, past table and tensors");
     static_assert(!PC || (((oQ - oL) / 4) % 64 == 40), "second window copy: conflict-free bank offset");
     float* sQ = PC ? reinterpret_cast<float*>(smem + oQ) : nullptr;

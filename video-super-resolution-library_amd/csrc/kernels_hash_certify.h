@@ -319,11 +319,15 @@ __device__ __forceinline__ void tensor_ac(const SepW& S, const GT* sG, float4* s
 // pays the approximate AND the exact work.  160 entries: measured 48 / 96 / 160 / 256 / 320 (scripts/r03_call28.sh, r03_call29.sh);
 // with 48, tiles of AVX2-flavour frames (twice the uncertified share: their table error is 6.5e-4) overflowed often enough that C1
 // ran 13 % (random frames: 21 %) slower than with 160, C2 / C3 / C5 1-2 %; beyond 160 nothing changes.
+// Round 6, on photographs (whose lists are longer: 1.2-8 % uncertified against 0.4 % on the synthetic frame, 3 % of the tiles past 160):
+// 256 entries -- all that fits (tensors behind the table in sV's space, one lane per entry in the hash round) -- C2 +2.4 %, C1 +4.4 %,
+// C2b +2.1 % on the photo frames, synthetic kinds unchanged (docs/EXPERIMENTS.md R6.11).
 #ifdef RAISR_EXP_OCC5
 constexpr unsigned kListMax = 88;
 #else
-constexpr unsigned kListMax = 160;
+constexpr unsigned kListMax = 256;
 #endif
+static_assert(kListMax <= 256, "the hash round of the worklist runs one lane per entry");
 
 // hash stage of k_hashfilter_ac for one tile: sG holds the gradient tile.  Leaves the buckets of the tile in sH / sH2
 // (0xFF: not filtered / no re-hash) and ends with a workgroup barrier.
