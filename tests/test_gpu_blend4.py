@@ -101,3 +101,27 @@ def test_resize_3_2_blocks_bit_exact(bits):
                     assert np.array_equal(got[:, :dw], ref), (bits, tie, sw, sh, pad, int((got[:, :dw] != ref).sum()))
                     assert not got[:, dw:].any()
         dev.close()
+
+
+def test_blend_families_agree_on_random_geometries():
+    """Seeded sweep: the four-columns-per-lane kernels (default) against the LDS-tile kernels (RAISR_HIP_BLEND_ROWS=0) on 36 random
+    geometries whose output width is a multiple of 4 (8 ... 2 100 columns, 14 ... 260 rows), 8 / 10 bit, fp32 and binary16 numerics,
+    one and two passes -- the whole output plane must agree (both families are separately pinned to the oracle above)."""
+    import synth
+    rng = np.random.default_rng(20260930)
+    variants = [("filters_2x/filters_highres", (2, 1), 8, 1, 1, 2), ("filters_2x/filters_highres", (2, 1), 10, 1, 1, 2),
+                ("filters_2x/filters_highres", (2, 1), 8, 1, 1, 5), ("filters_2x/filters_denoise", (2, 1), 8, 2, 2, 2),
+                ("filters_1.5x/filters_highres", (3, 2), 8, 1, 1, 2), ("filters_2x/filters_lowres", (2, 1), 8, 2, 1, 1)]
+    for i in range(36):
+        fold, (rn, rd), bits, passes, mode, asm = variants[i % len(variants)]
+        if rn == 2:
+            w = 2 * int(rng.integers(2, 526))               # output width 8 ... 2 100, a multiple of 4
+            h = int(rng.integers(7, 131))
+        else:
+            w = 8 * int(rng.integers(1, 175))               # 1.5x: output width 12 ... 2 088, a multiple of 12
+            h = 2 * int(rng.integers(5, 87))
+        case = ("x", fold, (rn, rd), bits, passes, mode, asm, bool(i & 1))
+        y = synth.random_y(w, h, bits, seed=1000 + i) if i % 3 else synth.natural_y(w, h, bits, seed=1000 + i)
+        a = _gpu(y, case, 0)
+        b = _gpu(y, case, 8)
+        assert np.array_equal(a, b), (i, fold, w, h, bits, passes, asm, int((a != b).sum()))
