@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void k_blend(const TOut* __restrict__ lr, cons
 // the two columns outside the wave (lane 63: column c0 + 256, every other lane: column c0 - 1); the left / right neighbours of a
 // lane's outer columns come from the adjacent lanes through DPP wave shifts (wave_shr:1 / wave_shl:1, whose `old` operand is
 // exactly that outside column for lane 0 / lane 63).  The 3-row window slides down in registers, rows are requested one ahead of
-// their use.  Arithmetic per pixel:
-// the very expressions of k_blend / k_blend16 (same operations, same order).
+// their use.  Arithmetic per pixel: the expressions of k_blend / k_blend16 (same operations, same order); the fp32 variant's final
+// integer clamp max(min(cvttps(floor v), hi), lo) is evaluated on the float (blend4_row: same integer for every input).
 // ------------------------------------------------------------------------------------------------
 template <typename TOut> struct Lr4;
 template <> struct Lr4<uint8_t> {

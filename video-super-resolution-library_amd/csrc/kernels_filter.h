@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 4) void k_hashfilter(const T* __restrict__ lr,
 // numerics.  Same tile, same LR window, same filter stage; the structure tensor costs ~90 instead of ~605 lane-ops per
 // pixel and the hash ~100 instead of ~200; the few pixels whose bucket cannot be certified take the exact code.
 // PART (development builds, RAISR_HIP_AC_PART): 0 = the production kernel, 1 = hash stage only, 2 = filter stage only.
-// Four workgroups per CU (16 waves): 128 VGPRs and 40 384 B of LDS (4 x 40 960 = the CU's 160 KB).  Round 2 ran three (144 VGPRs,
+// Four workgroups per CU (16 waves): <= 128 VGPRs and <= 40 960 B of LDS each (4 x 40 960 = the CU's 160 KB; round 6: 100 / 108 VGPRs, 40 912 B).  Round 2 ran three (144 VGPRs,
 // 41 408 B): the fourth costs nothing but the two measures below -- the exact path's approximation table shares sV's space, and the
 // filter stage's tap offsets are kept as ONE register each -- and buys 12 % (1080p -> 4K: 192 -> 170 us isolated).
 // one 64 x 16 tile (tile column bx, tile row by) of k_hashfilter_ac: LR window -> gradient tile -> certified hash stage -> filter stage
