@@ -255,18 +255,18 @@ __global__ __launch_bounds__(256) void k_resize3x2(const TIn* __restrict__ src, 
         }
         TOut* p = dst + (size_t)y * R.dpitch + x0;
         if (vec) {
+            typedef unsigned u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));      // the block starts on a 4-byte, not a 16-byte boundary: says so
             if (sizeof(TOut) == 1) {
-                unsigned w[3];
+                u32x3a4 w;
 #pragma unroll
                 for (int k = 0; k < 3; k++) w[k] = (o[4 * k] & 0xffu) | ((o[4 * k + 1] & 0xffu) << 8) | ((o[4 * k + 2] & 0xffu) << 16) | (o[4 * k + 3] << 24);
-                *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);          // (two stores: the block is 4-byte, not 16-byte aligned)
-                reinterpret_cast<unsigned*>(p)[2] = w[2];
+                *reinterpret_cast<u32x3a4*>(p) = w;
             } else {
-                unsigned w[6];
+                u32x3a4 w0, w1;
 #pragma unroll
-                for (int k = 0; k < 6; k++) w[k] = (o[2 * k] & 0xffffu) | (o[2 * k + 1] << 16);
-#pragma unroll
-                for (int k = 0; k < 3; k++) reinterpret_cast<uint2*>(p)[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+                for (int k = 0; k < 3; k++) { w0[k] = (o[2 * k] & 0xffffu) | (o[2 * k + 1] << 16); w1[k] = (o[6 + 2 * k] & 0xffffu) | (o[7 + 2 * k] << 16); }
+                *reinterpret_cast<u32x3a4*>(p) = w0;                        // (a 3-vector occupies 16 bytes as an array element: address the second half by hand)
+                *reinterpret_cast<u32x3a4*>(p + 6) = w1;
             }
         } else {
             for (int i = 0; i < 12 && x0 + i < R.dw; i++) p[i] = (TOut)o[i];
